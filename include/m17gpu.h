@@ -1,0 +1,171 @@
+/*
+ * m17gpu.h -- C-ABI of the MI355X-native M17 receive chain.
+ *
+ * This is the drop-in boundary for the receive hot path of G4GUO/m17_sdr
+ * (reference tree m17gismo/): one process-wide shared library, `extern "C"`,
+ * plain pointers and sizes.  The reference runs ONE channel per process through
+ * file-static state; this core is re-entrant and batched:
+ * an explicit context holds the per-channel state of C independent 48 kHz
+ * channels in HBM and every entry point processes all of them in one launch.
+ *
+ * Pointer convention: arguments named d_* are DEVICE pointers (HBM, e.g. from
+ * hipMalloc or torch.Tensor.data_ptr()); h_* are host pointers.  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  All calls are
+ * asynchronous on `stream` unless stated.  Return value: 0 = ok, <0 = error
+ * (m17gpu_last_error() gives the text).  There is NO CPU fallback: without a
+ * HIP device every compute entry point fails with M17GPU_ERR_NO_DEVICE.
+ *
+ * Citations (file:line) name the reference interface each entry replaces.
+ */
+#ifndef M17GPU_H
+#define M17GPU_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M17GPU_BLOCK_SAMPLES 1920   /* m17defines.h:17  N_SAMPLES (40 ms @ 48 kHz) */
+#define M17GPU_DISC_OUT       384   /* m17_dsp.cpp:463  N_SAMPLES/5 */
+#define M17GPU_FRAME_SYMS     192   /* m17defines.h:66  FRAME_SYM_LENGTH */
+#define M17GPU_SOFT_BITS      368   /* 184 payload symbols x 2 */
+#define M17GPU_SYM_STRIDE(nblk) ((size_t)(nblk) * 193 + 8)  /* floats per channel in d_syms */
+
+#define M17GPU_OK             0
+#define M17GPU_ERR_NO_DEVICE (-1)
+#define M17GPU_ERR_HIP       (-2)
+#define M17GPU_ERR_ARG       (-3)
+#define M17GPU_ERR_NOMEM     (-4)
+
+/* frame-record flags */
+#define M17GPU_F_SYNC_OK    0x0001  /* m17_locked_sync_check passed   (m17_rx_frame.cpp:93-103) */
+#define M17GPU_F_PARSED     0x0002  /* m17_rx_parse was invoked       (m17_rx_frame.cpp:142,151) */
+#define M17GPU_F_LICH_OK    0x0004  /* update_lich found CRC==0       (m17_rx_parse.cpp:78-83) */
+#define M17GPU_F_DELIVERED  0x0008  /* payload handed to the sink     (m17_rx_parse.cpp:148-158) */
+#define M17GPU_F_EOT        0x0010  /* EOT sync, framer unlocked      (m17_rx_frame.cpp:136-139) */
+#define M17GPU_F_LOST       0x0020  /* > N_FERROR bad syncs, unlocked (m17_rx_frame.cpp:145-149) */
+#define M17GPU_F_LSF_GATE   0x0040  /* decode_link_frame's CRC gate   (m17_rx_parse.cpp:98, quirk H9) */
+#define M17GPU_F_PKT_VALID  0x0080  /* parse_packet CRC==0 at EOF     (m17_rx_parse.cpp:42-45) */
+#define M17GPU_F_AOS        0x0100  /* lock acquired, not a frame     (m17_rx_frame.cpp:165-169) */
+
+/* One 64-byte record per framer event of one channel, in event order.
+ * It carries what the reference hands to its sinks (m17_net_new_rx_data
+ * m17_net.cpp:53, m17_db_golay_errors m17_dbase.cpp:79, m17_aos/m17_los :60-75). */
+typedef struct {
+    uint8_t  type;          /* sync class 0..5: preamble, LSF, stream, packet, BERT, EOT */
+    uint8_t  votes;         /* sign mismatches against the winning template */
+    uint8_t  golay_errs;    /* stream frames: sum of the four Golay weights */
+    uint8_t  frame_errors;  /* m_frame_errors after this frame */
+    uint16_t flags;         /* M17GPU_F_* */
+    uint16_t fn;            /* stream: frame number; packet: (eof<<8)|fn */
+    float    variance;      /* amplitude spread of the 8 sync symbols */
+    uint32_t block;         /* 1920-sample block index since reset */
+    uint16_t sym_pos;       /* index of the completing symbol inside that block */
+    uint16_t rsv0;
+    uint8_t  data[32];      /* LSF: 30 B | stream: LICH chunk[6] + FN/payload[18] | packet: 26 B */
+    uint8_t  rsv[12];
+} m17gpu_rec;
+
+typedef struct m17gpu_ctx m17gpu_ctx;
+
+/* ---------------- lifecycle ---------------- */
+/* Builds the tables the reference builds in main.cpp:110-118 (CRC LUT, conv
+ * LUT, de-randomiser bits, Golay tables, 2x40x31 polyphase RRC taps), uploads
+ * them, and allocates state + workspace for n_channels channels and up to
+ * max_blocks 1920-sample blocks per call.  Synchronous. */
+int  m17gpu_create(m17gpu_ctx **ctx, int n_channels, int max_blocks, int device);
+void m17gpu_destroy(m17gpu_ctx *ctx);
+/* zero-initialised statics + m17_rx_sync_init's m_clk=1,m_thr=0,m_index=10 */
+int  m17gpu_reset(m17gpu_ctx *ctx, void *stream);
+const char *m17gpu_last_error(void);
+int  m17gpu_device_count(void);            /* 0 when no HIP device is visible */
+int  m17gpu_channels(const m17gpu_ctx *ctx);
+
+/* ---------------- the hot path ---------------- */
+/* Batched m17_dsp_rx (m17_dsp.cpp:461-476) over C channels x nblk blocks.
+ *   d_iq     [C][nblk][1920][2] int16  (scmplx, m17defines.h:130-133)
+ *   mode     0 = front end only (discriminator, timing recovery, sync
+ *                correlator/framer; records carry sync fields only)
+ *            1 = full chain (+ demap, de-randomise, de-interleave, de-puncture,
+ *                Viterbi, Golay, LICH/LSF bookkeeping)
+ *   d_recs   [C][rec_cap] records, d_counts [C] number of events per channel
+ *            (events beyond rec_cap are counted, not stored)
+ *   d_syms   optional [C][M17GPU_SYM_STRIDE(nblk)] recovered symbols
+ *            (m17_rx_sync_samples output), d_nsyms optional [C][nblk] counts */
+int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
+                     m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts,
+                     float *d_syms, int32_t *d_nsyms, void *stream);
+
+/* ---------------- stage entry points (batched reference functions) -------- */
+/* dsp_short_to_float + dsp_limit + dsp_arctan_disc2 (m17_dsp.cpp:136-141,
+ * :412-419, :194-222): d_disc [C][nblk][384] DC-removed discriminator output,
+ * d_offset [C][nblk] the per-block DC estimate.  Advances z[2] state. */
+int m17gpu_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk,
+                    float *d_disc, float *d_offset, void *stream);
+/* m17_rx_sync_samples + m17_rx_symbols without the parse (m17_rx_sync.cpp:77-99,
+ * m17_rx_frame.cpp:126-177) from a discriminator stream d_disc [C][nblk][384]. */
+int m17gpu_sync_frame(m17gpu_ctx *ctx, const float *d_disc, int nblk,
+                      m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts,
+                      float *d_syms, int32_t *d_nsyms, void *stream);
+/* m17_viterbi_decode (m17_conv.cpp:148-168) on n independent soft-bit vectors:
+ * d_soft [n][len] floats -> d_bits [n][len/2] one bit per byte.  len <= 488, even. */
+int m17gpu_viterbi_decode(m17gpu_ctx *ctx, const float *d_soft, uint8_t *d_bits,
+                          int len, int n, void *stream);
+/* m17_dsp_demap_frame (m17_dsp.cpp:82-95): d_sym [n][192] -> d_soft [n][368] */
+int m17gpu_demap_frame(m17gpu_ctx *ctx, const float *d_sym, float *d_soft, int n, void *stream);
+/* stateless part of m17_rx_parse (m17_rx_parse.cpp:86-177): frame symbols
+ * d_sym [n][192] + d_type [n] -> data/fn/golay_errs of d_recs [n]; no LICH state. */
+int m17gpu_decode_frames(m17gpu_ctx *ctx, const float *d_sym, const uint8_t *d_type,
+                         m17gpu_rec *d_recs, int n, void *stream);
+/* m_17_golay_decode (m17_golay.cpp:103-116) on n 24-bit words: d_out[i] = data | weight<<12 */
+int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_out, int n, void *stream);
+
+/* ---------------- state access (host, synchronous) ---------------- */
+/* the reassembled LSF pair m_lsf[2][30] of each channel (m17_rx_parse.cpp:5) */
+int m17gpu_get_lsf(m17gpu_ctx *ctx, uint8_t *h_lsf /* [C][2][30] */);
+/* g_errors, n_frames, in_frame, frame_id_epoch per channel (m17_dbase.cpp:60-82) */
+int m17gpu_get_counters(m17gpu_ctx *ctx, uint32_t *h_cnt /* [C][4] */);
+/* m17_rx_lock() of every channel (m17_rx_frame.cpp:187-189) */
+int m17gpu_get_lock(m17gpu_ctx *ctx, uint8_t *h_lock /* [C] */);
+/* host copies of the uploaded tables, for inspection / tests */
+int m17gpu_get_taps(float *h_mf /* [40][31] */, float *h_md /* [40][31] */);
+int m17gpu_get_golay_tables(uint16_t *h_enc /* [4096] */, uint16_t *h_err /* [4096] */);
+
+/* ---------------- synthetic signal source (host) ----------------
+ * A restatement of the reference transmitter (framer m17_tx_routines.cpp:24-255,
+ * 4-FSK modulator m17_modulate.cpp:22-86, 10 samples/symbol) used to produce
+ * the benchmark / test IQ.  Not on the hot path. */
+typedef struct {
+    uint64_t seed;            /* per-channel PRNG seed (splitmix64) */
+    int32_t  n_stream_frames; /* stream frames per transmission */
+    int32_t  delay_samples;   /* un-modulated carrier samples prepended (0..1919) */
+    float    ebn0_db;         /* AWGN level; >= 100 means noiseless */
+    int32_t  packet_mode;     /* 0 = stream transmissions, 1 = packet-mode bursts */
+} m17gen_params;
+
+/* h_iq [nblk*1920*2]; h_lsf [30] the LSF sent (incl. CRC); h_payload
+ * [max_payload_frames][16] the stream payloads in transmit order; returns the
+ * number of stream frames fully generated (or <0). */
+int m17gen_channel(const m17gen_params *p, int nblk, int16_t *h_iq,
+                   uint8_t *h_lsf, uint8_t *h_payload, int max_payload_frames);
+/* C channels, channel c uses seed base_seed + c and delay (hash of c) % 1920;
+ * h_iq [C][nblk][1920][2]; h_lsf [C][30]; h_payload [C][max_payload_frames][16];
+ * h_nframes [C]; nthreads host threads. */
+int m17gen_batch(int C, uint64_t base_seed, int first_channel, int nblk, int n_stream_frames,
+                 float ebn0_db, int packet_mode, int16_t *h_iq, uint8_t *h_lsf,
+                 uint8_t *h_payload, int max_payload_frames, int32_t *h_nframes, int nthreads);
+/* transmit-side codec pieces, exposed for round-trip tests */
+int m17gen_stream_frame_dibits(const uint8_t lsf[30], int lich_count, uint16_t fn,
+                               const uint8_t payload[16], uint8_t dibits[192]);
+int m17gen_lsf_frame_dibits(const uint8_t lsf[30], uint8_t dibits[192]);
+int m17gen_packet_frame_dibits(const uint8_t *payload, int len, int eof, int nf, uint8_t dibits[192]);
+int m17gen_build_lsf(uint64_t dst, uint64_t src, uint16_t type_word, const uint8_t meta[14], uint8_t lsf[30]);
+uint64_t m17gen_encode_call(const char *call9);
+/* modulate n dibits (value 0..3, or 255 = zero deviation) appending 10 samples each */
+int m17gen_modulate(const uint8_t *dibits, int n, int16_t *h_iq, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M17GPU_H */

@@ -1,0 +1,766 @@
+/*
+ * m17_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the G4GUO/m17_sdr receive hot path; see
+ * m17_oracle.h for the pin status.  Build with
+ *     gcc -O2 -ffp-contract=off -fno-fast-math (no -march=native)
+ * so that every float expression is evaluated as separate IEEE binary32
+ * operations exactly as the reference's `g++ -O3` x86-64 (SSE2, no FMA) build
+ * does.
+ *
+ * Citations are relative to /root/reference/m17gismo/.
+ */
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#include "m17_oracle.h"
+
+/* ------------------------------------------------------------------ */
+/* tables                                                             */
+/* ------------------------------------------------------------------ */
+static uint16_t t_crc[256];            /* m17_crc.cpp:6 */
+static uint8_t  t_clut[32][2];         /* m17_conv.cpp:22 */
+static uint8_t  t_bf[16][4];           /* m17_conv.cpp:93-108 as {w,x,y,z} */
+static uint8_t  t_derand[368];         /* m17_correlate.cpp:9 */
+static uint16_t t_genc[4096];          /* m17_golay.cpp:19 */
+static uint16_t t_gerr[4096];          /* m17_golay.cpp:28 */
+static float    t_mf[M17O_NF][M17O_FN];/* m17_rx_sync.cpp:12 */
+static float    t_md[M17O_NF][M17O_FN];/* m17_rx_sync.cpp:13 */
+static int      t_init_done;
+
+/* M17 sync templates, +-1 per symbol (m17_rx_frame.cpp:5-12) */
+static const float t_sframe[6][8] = {
+    { 1,-1, 1,-1, 1,-1, 1,-1},   /* 0 preamble            */
+    { 1, 1, 1, 1,-1,-1, 1,-1},   /* 1 link setup  0x55F7  */
+    {-1,-1,-1,-1, 1, 1,-1, 1},   /* 2 stream      0xFF5D  */
+    { 1,-1, 1, 1,-1,-1,-1,-1},   /* 3 packet      0x75FF  */
+    {-1, 1,-1,-1, 1, 1, 1, 1},   /* 4 BERT        0xDF55  */
+    { 1, 1, 1, 1, 1, 1,-1, 1}    /* 5 EOT                 */
+};
+
+/* de-randomiser bytes: M17 spec randomising sequence (m17_correlate.cpp:3-7) */
+static const uint8_t t_ctab[46] = {
+    0xD6,0xB5,0xE2,0x30,0x82,0xFF,0x84,0x62,0xBA,0x4E,0x96,0x90,0xD8,0x98,0xDD,0x5D,
+    0x0C,0xC8,0x52,0x43,0x91,0x1D,0xF8,0x6E,0x68,0x2F,0x35,0xDA,0x14,0xEA,0xCD,0x76,
+    0x19,0x8D,0xD5,0x80,0xD1,0x33,0x87,0x13,0x57,0x18,0x2D,0x29,0x78,0xC3 };
+
+/* Golay(24,12) parity generator rows, M17 spec (m17_golay.cpp:11) */
+static const uint16_t t_gtab[12] = {
+    0xC75,0x63B,0xF68,0x7B4,0x3DA,0xD99,0x6CD,0x367,0xDC6,0xA97,0x93E,0x8EB };
+
+/* puncture patterns, M17 spec (m17_puncture.cpp:4-10) */
+static const uint8_t t_p1[61] = {
+    1,1,0,1,1,1,0,1,1,1,0,1,1,1,0,1,1,1,0,1,1,1,0,1,1,1,0,1,1,1,0,1,1,1,0,1,1,1,0,1,
+    1,1,0,1,1,1,0,1,1,1,0,1,1,1,0,1,1,1,0,1,1 };
+static const uint8_t t_p2[12] = {1,1,1,1,1,1,1,1,1,1,1,0};
+static const uint8_t t_p3[8]  = {1,1,1,1,1,1,1,0};
+
+/* m17_crc.cpp:8-22 : poly 0x5935, MSB first */
+static void build_crc(void)
+{
+    for (int i = 0; i < 256; i++) {
+        uint16_t x = (uint16_t)(i << 8);
+        for (int n = 0; n < 8; n++)
+            x = (x & 0x8000) ? (uint16_t)((x << 1) ^ 0x5935) : (uint16_t)(x << 1);
+        t_crc[i] = x;
+    }
+}
+
+/* m17_conv.cpp:24-29 (G1 = 0x19, G2 = 0x17 over a 5-bit register) and the
+ * butterfly table :93-108, derived the way the commented generator :117-144 did */
+static void build_conv(void)
+{
+    for (int i = 0; i < 32; i++) {
+        t_clut[i][0] = ((i >> 4) ^ (i >> 1) ^ i) & 1;
+        t_clut[i][1] = ((i >> 4) ^ (i >> 3) ^ (i >> 2) ^ i) & 1;
+    }
+    for (int v = 0; v < 16; v++) {
+        int s0 = (v << 1), s1 = (v << 1) + 1;
+        t_bf[v][0] = (uint8_t)(s0 & 0xF);
+        t_bf[v][1] = (uint8_t)((t_clut[s0][0] << 1) + t_clut[s0][1]);
+        t_bf[v][2] = (uint8_t)(s1 & 0xF);
+        t_bf[v][3] = (uint8_t)((t_clut[s1][0] << 1) + t_clut[s1][1]);
+    }
+}
+
+/* m17_correlate.cpp:35-42 */
+static void build_derand(void)
+{
+    int idx = 0;
+    for (int i = 0; i < 46; i++)
+        for (int n = 0x80; n; n >>= 1)
+            t_derand[idx++] = (t_ctab[i] & n) ? 1 : 0;
+}
+
+/* m17_golay.cpp:31-72.  The error table is filled by visiting all 2^24 words
+ * in ascending order and letting the last writer win, exactly like :57-71, so
+ * weight-4 syndromes resolve to the numerically largest pattern. */
+static void build_golay(void)
+{
+    for (int i = 0; i < 0x1000; i++) {
+        uint16_t p = 0; int m = 0x800;
+        for (int n = 0; n < 12; n++) { if (i & m) p ^= t_gtab[n]; m >>= 1; }
+        t_genc[i] = p;
+    }
+    memset(t_gerr, 0, sizeof t_gerr);
+    for (int i = 0; i < 0xFFF; i++) t_gerr[i] = 0x400;       /* :53-55 as written */
+    for (uint32_t w = 0; w < 0x1000000u; w++) {
+        int bits = __builtin_popcount(w);
+        if (bits < 5) {
+            uint16_t data = (uint16_t)(w >> 12), par = (uint16_t)(w & 0xFFF);
+            uint16_t syn = par ^ t_genc[data];
+            t_gerr[syn] = (uint16_t)((bits << 12) | data);
+        }
+    }
+}
+
+/* m17_dsp.cpp:295-315 */
+void m17o_build_rrc_filter(float *filter, float rolloff, int ntaps, int sps)
+{
+    double a, b, c, d;
+    double B = (rolloff + 0.0001);
+    double t = -(ntaps - 1) / 2;          /* integer division on purpose (:298) */
+    double Ts = sps;
+    for (int i = 0; i < ntaps; i++) {
+        a = 2.0 * B / (M_PI * sqrt(Ts));
+        b = cos((1.0 + B) * M_PI * t / Ts);
+        if (t == 0)
+            c = (1.0 - B) * M_PI / (4 * B);
+        else
+            c = sin((1.0 - B) * M_PI * t / Ts) / (4.0 * B * t / Ts);
+        d = (1.0 - (4.0 * B * t / Ts) * (4.0 * B * t / Ts));
+        filter[i] = (float)(a * (b + c) / d);
+        t = t + 1.0;
+    }
+}
+
+/* m17_dsp.cpp:420-429 */
+void m17o_set_filter_gain(float *f, float gain, int stride, int ntaps)
+{
+    float sum = 0;
+    for (int i = 0; i < ntaps; i++) sum += f[i * stride];
+    gain = gain / sum;
+    for (int i = 0; i < ntaps; i++) f[i * stride] = f[i * stride] * gain;
+}
+
+/* m17_rx_sync.cpp:101-122 */
+static void build_sync_filters(void)
+{
+    enum { N = M17O_NF * M17O_FN };
+    static float mf[N], md[N];
+    m17o_build_rrc_filter(mf, 0.5f, N, M17O_NF * 2);
+    for (int i = 0; i < N; i++)
+        md[i] = mf[(i + 1) % N] - mf[(i + N - 1) % N];
+    for (int i = 0; i < M17O_NF; i++)
+        for (int j = 0; j < M17O_FN; j++) {
+            t_mf[i][j] = mf[i + j * M17O_NF];
+            t_md[i][j] = md[i + j * M17O_NF];
+        }
+    for (int i = 0; i < M17O_NF; i++)
+        m17o_set_filter_gain(t_mf[i], 1.0f, 1, M17O_FN);
+}
+
+void m17o_init(void)
+{
+    if (t_init_done) return;
+    build_crc();
+    build_conv();
+    build_derand();
+    build_golay();
+    build_sync_filters();
+    t_init_done = 1;
+}
+
+const float *m17o_tab_mf(void) { return &t_mf[0][0]; }
+const float *m17o_tab_md(void) { return &t_md[0][0]; }
+const uint16_t *m17o_tab_golay_enc(void) { return t_genc; }
+const uint16_t *m17o_tab_golay_err(void) { return t_gerr; }
+const uint8_t *m17o_tab_derand(void) { return t_derand; }
+const uint16_t *m17o_tab_crc(void) { return t_crc; }
+int m17o_sizeof_chan(void) { return (int)sizeof(m17o_chan); }
+
+/* zero-initialised statics + m17_rx_sync.cpp:123-126 */
+void m17o_chan_reset(m17o_chan *st)
+{
+    memset(st, 0, sizeof *st);
+    st->m_clk = 1;
+    st->m_thr = 0;
+    st->m_index = 10;
+}
+
+/* ------------------------------------------------------------------ */
+/* codec primitives                                                   */
+/* ------------------------------------------------------------------ */
+/* m17_crc.cpp:26-35 */
+uint16_t m17o_crc(const uint8_t *in, int len)
+{
+    uint16_t crc = 0xFFFF;
+    for (int i = 0; i < len; i++) {
+        uint8_t pos = (uint8_t)((crc >> 8) ^ in[i]);
+        crc = (uint16_t)((crc << 8) ^ t_crc[pos]);
+    }
+    return crc;
+}
+
+/* m17_golay.cpp:94-102 */
+uint32_t m17o_golay_encode(uint16_t data)
+{
+    return ((uint32_t)data << 12) | t_genc[data & 0xFFF];
+}
+
+/* m17_golay.cpp:103-116 */
+int m17o_golay_decode(uint32_t word, uint16_t *odata)
+{
+    uint16_t data = (word >> 12) & 0xFFF, par = word & 0xFFF;
+    uint16_t syn = par ^ t_genc[data];
+    *odata = data ^ (t_gerr[syn] & 0xFFF);
+    return (t_gerr[syn] & 0xF000) >> 12;
+}
+
+/* m17_conv.cpp:53-71 */
+int m17o_conv_encode_8(const uint8_t *in, uint8_t *out, int len)
+{
+    int idx = 0; uint8_t sr = 0;
+    for (int i = 0; i < len; i++)
+        for (int n = 0x80; n; n >>= 1) {
+            if (in[i] & n) sr |= 0x10;
+            out[idx++] = t_clut[sr][0];
+            out[idx++] = t_clut[sr][1];
+            sr >>= 1;
+        }
+    for (int i = 0; i < 4; i++) {
+        out[idx++] = t_clut[sr][0];
+        out[idx++] = t_clut[sr][1];
+        sr >>= 1;
+    }
+    return idx;
+}
+
+/* m17_conv.cpp:33-49 */
+int m17o_conv_encode_1(const uint8_t *in, uint8_t *out, int len)
+{
+    int idx = 0; uint8_t sr = 0;
+    for (int i = 0; i < len; i++) {
+        if (in[i]) sr |= 0x10;
+        out[idx++] = t_clut[sr][0];
+        out[idx++] = t_clut[sr][1];
+        sr >>= 1;
+    }
+    for (int i = 0; i < 4; i++) {
+        out[idx++] = t_clut[sr][0];
+        out[idx++] = t_clut[sr][1];
+        sr >>= 1;
+    }
+    return idx;
+}
+
+static const uint8_t *punc_tab(int which, int *period)
+{
+    switch (which) {
+    case 1: *period = 61; return t_p1;
+    case 2: *period = 12; return t_p2;
+    default: *period = 8; return t_p3;
+    }
+}
+
+/* m17_puncture.cpp:12-41; len = input length */
+int m17o_punc(int which, const uint8_t *in, uint8_t *out, int len)
+{
+    int per; const uint8_t *p = punc_tab(which, &per);
+    int idx = 0;
+    for (int i = 0; i < len; i++)
+        if (p[i % per]) out[idx++] = in[i];
+    return idx;
+}
+
+/* m17_puncture.cpp:47-79; len = OUTPUT length, erasures become 0.0f */
+int m17o_de_punc(int which, const float *in, float *out, int len)
+{
+    int per; const uint8_t *p = punc_tab(which, &per);
+    int odx = 0, idx = 0;
+    for (int i = 0; i < len; i++) {
+        if (p[i % per]) out[odx++] = in[idx++];
+        else            out[odx++] = 0.0f;
+    }
+    return odx;
+}
+
+/* m17_interleave.cpp:3-7 */
+void m17o_interleave_u8(const uint8_t *in, uint8_t *out, int len)
+{
+    for (int i = 0; i < len; i++) out[((i * 45) + (92 * i * i)) % 368] = in[i];
+}
+
+/* m17_interleave.cpp:8-12 */
+void m17o_de_interleave(const float *in, float *out, int len)
+{
+    for (int i = 0; i < len; i++) out[((i * 45) + (92 * i * i)) % 368] = in[i];
+}
+
+/* m17_correlate.cpp:16-20 */
+void m17o_de_correlate_u8(const uint8_t *in, uint8_t *out, int len)
+{
+    for (int i = 0; i < len; i++) out[i] = (in[i] ^ t_derand[i % 368]) & 1;
+}
+
+/* m17_correlate.cpp:27-31 (in == out allowed) */
+void m17o_de_correlate_f(const float *in, float *out, int len)
+{
+    for (int i = 0; i < len; i++) out[i] = t_derand[i % 368] ? -in[i] : in[i];
+}
+
+/* m17_conv.cpp:73-113 + :148-168.  Correlation metric, strict '>' keeps the
+ * even predecessor, ties go to the odd one; traceback from state 0 emitting the
+ * MSB of the predecessor (so out[0] is always 0). */
+int m17o_viterbi_decode(const float *in, uint8_t *out, int len)
+{
+    float acm[16], tm[16];
+    static __thread uint8_t path[16][1024];
+    int hp = 0;
+    memset(acm, 0, sizeof acm);
+    acm[0] = 1.0f;
+    for (int i = 0; i < len; i += 2) {
+        float m1 = in[i], m2 = in[i + 1];
+        float metric1X = m1, metric0X = -m1, metricX1 = m2, metricX0 = -m2;
+        float metric[4];
+        metric[0] = (metric0X + metricX0);
+        metric[1] = (metric0X + metricX1);
+        metric[2] = (metric1X + metricX0);
+        metric[3] = (metric1X + metricX1);
+        for (int v = 0; v < 16; v++) {
+            int w = t_bf[v][0], x = t_bf[v][1], y = t_bf[v][2], z = t_bf[v][3];
+            float ta = acm[w] + metric[x];
+            float tb = acm[y] + metric[z];
+            if (ta > tb) { tm[v] = ta; path[v][hp] = (uint8_t)w; }
+            else         { tm[v] = tb; path[v][hp] = (uint8_t)y; }
+        }
+        for (int v = 0; v < 16; v++) acm[v] = tm[v];
+        hp++;
+    }
+    uint8_t state = 0;
+    for (int i = hp - 1; i >= 0; i--) {
+        state = path[state][i];
+        out[i] = (state & 0x08) ? 1 : 0;
+    }
+    return hp;
+}
+
+/* m17_bit_utils.cpp:180-187 */
+uint32_t m17o_hard_decode_24(const float *in)
+{
+    uint32_t w = 0;
+    for (int i = 0; i < 24; i++) { w <<= 1; w |= (in[i] >= 0) ? 1 : 0; }
+    return w;
+}
+
+/* m17_bit_utils.cpp:26-32 */
+int m17o_pack_1_to_8(const uint8_t *in, uint8_t *out, int len)
+{
+    int idx = 0;
+    for (int i = 0; i < len; i += 8)
+        out[idx++] = (uint8_t)((in[i] << 7) | (in[i+1] << 6) | (in[i+2] << 5) | (in[i+3] << 4) |
+                               (in[i+4] << 3) | (in[i+5] << 2) | (in[i+6] << 1) | in[i+7]);
+    return idx;
+}
+
+/* m17_dsp.cpp:35-42 + :82-95.  fabs() on a float picks the float overload in
+ * the reference's C++; `fabs(m) - 0.6666` and `8.0/sum` are double. */
+void m17o_demap_frame(const float *in, float *out)
+{
+    float sum = 0;
+    for (int i = 0; i < 8; i++) sum += fabsf(in[i]);
+    float cor = (float)(8.0 / (double)sum);
+    int idx = 0;
+    for (int i = 8; i < M17O_FRAME_SYMS; i++) {
+        float m = in[i] * cor;
+        out[idx]     = -m;
+        out[idx + 1] = (float)((double)fabsf(m) - 0.6666);
+        idx += 2;
+    }
+}
+
+/* m17_bit_utils.cpp:191-208 */
+uint64_t m17o_encode_call(const char *call)
+{
+    uint64_t word = 0;
+    for (int i = 8; i >= 0; i--) {
+        word *= 40;
+        char ch = call[i];
+        if (ch >= 'A' && ch <= 'Z') word += (uint64_t)(ch - 'A' + 1);
+        else if (ch >= '0' && ch <= '9') word += (uint64_t)(ch - '0' + 27);
+        else {
+            if (ch == '-') word += 37;
+            if (ch == '/') word += 38;
+            if (ch == '.') word += 39;
+        }
+    }
+    return word;
+}
+
+/* m17_bit_utils.cpp:209-226 */
+void m17o_decode_call(uint64_t word, char *call)
+{
+    if (word == 0xFFFFFFFFFFFFull) { strcpy(call, "BROADCAST"); return; }
+    for (int i = 8; i >= 0; i--) {
+        int ch = (int)(word % 40);
+        if (ch == 0) call[8 - i] = ' ';
+        if (ch == 37) call[8 - i] = '-';
+        if (ch == 38) call[8 - i] = '/';
+        if (ch == 39) call[8 - i] = '.';
+        if (ch >= 1 && ch <= 26) call[8 - i] = (char)(ch + 'A' - 1);
+        if (ch >= 27 && ch <= 36) call[8 - i] = (char)(ch + '0' - 27);
+        word /= 40;
+    }
+    call[9] = 0;
+}
+
+/* m17_prbs9.cpp:16-32 : x^9 + x^5 + 1, start 0x001 */
+void m17o_prbs9(uint8_t *out, int len)
+{
+    uint16_t sr = 1;
+    for (int i = 0; i < len; i++) {
+        uint8_t bit = ((sr >> 8) ^ (sr >> 4)) & 1;
+        sr = (uint16_t)(((sr << 1) | bit) & 0x1FF);
+        out[i] = bit;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* streaming stages                                                   */
+/* ------------------------------------------------------------------ */
+/* m17_dsp.cpp:136-141 (int16 * 0.00003 in double, rounded to float),
+ * :412-419 (limiter: float sqrt, reciprocal in double), :194-222 (discriminator,
+ * /5 pick, sequential DC sum over all 1920 samples, DC removal). */
+void m17o_frontend(m17o_chan *st, const int16_t *iq, float *d, float *d_raw, float *offset_out)
+{
+    float offset = 0;
+    int idx = 0;
+    float z0re = st->z0re, z0im = st->z0im, z1re = st->z1re, z1im = st->z1im;
+    int count = st->disc_count;
+    for (int i = 0; i < M17O_BLOCK_SAMPLES; i++) {
+        float re = (float)((double)iq[2 * i] * 0.00003);
+        float im = (float)((double)iq[2 * i + 1] * 0.00003);
+        float m = sqrtf(re * re + im * im);
+        float g = (float)(1.0 / (double)m);
+        re = re * g;
+        im = im * g;
+        float a = z0im * (re - z1re);
+        float b = z0re * (im - z1im);
+        float u = b - a;
+        z1re = z0re; z1im = z0im;
+        z0re = re;   z0im = im;
+        count = (count + 1) % 5;
+        if (count == 0) d[idx++] = u * 0.5f;
+        offset += u * 0.5f;
+    }
+    st->z0re = z0re; st->z0im = z0im; st->z1re = z1re; st->z1im = z1im;
+    st->disc_count = count;
+    if (d_raw) memcpy(d_raw, d, sizeof(float) * (size_t)idx);
+    offset = offset / M17O_BLOCK_SAMPLES;
+    for (int i = 0; i < idx; i++) d[i] = d[i] - offset;
+    if (offset_out) *offset_out = offset;
+}
+
+/* m17_rx_sync.cpp:25-31 */
+static float sync_filter(const float *in, const float *c)
+{
+    float sum = in[0] * c[0];
+    for (int i = 1; i < M17O_FN; i++) sum += in[i] * c[i];
+    return sum;
+}
+
+/* m17_rx_sync.cpp:77-99 with :32-42 and :45-72.
+ * `out[-1]` (m_idx-- at m_idx==0, :69) is undefined behaviour in the reference;
+ * here the symbol written to index -1 is discarded. */
+int m17o_rx_sync_samples(m17o_chan *st, const float *in, float *out, int len)
+{
+    int m_idx = 0;
+    for (int i = 0; i < len; i++) {
+        for (int k = 0; k < M17O_FN - 1; k++) st->m_buff[k] = st->m_buff[k + 1];
+        st->m_buff[M17O_FN - 1] = in[i];
+        st->m_clk = (st->m_clk + 1) % 2;
+        if (st->m_clk) {
+            st->sum = sync_filter(st->m_buff, t_mf[st->m_index]);
+            st->dif = sync_filter(st->m_buff, t_md[st->m_index]);
+            if (m_idx >= 0) out[m_idx] = st->sum;
+            m_idx++;
+        } else {
+            float sum = st->sum, dif = st->dif;
+            if (sum < 0) dif = -dif;
+            if (dif > 0) st->m_thr++;
+            if (dif < 0) st->m_thr--;
+            int thresh = st->m_flock ? 80 : 10;
+            if (st->m_thr > thresh) {
+                st->m_index = (st->m_index + 1) % M17O_NF;
+                st->m_thr = 0;
+                if (st->m_index == 0) {
+                    st->m_clk = 1;
+                    if (m_idx >= 0) out[m_idx] = 0;
+                    m_idx++;
+                }
+            }
+            if (st->m_thr < -thresh) {
+                st->m_thr = 0;
+                st->m_index = (st->m_index + M17O_NF - 1) % M17O_NF;
+                if (st->m_index == (M17O_NF - 1)) {
+                    st->m_clk = 1;
+                    m_idx--;
+                }
+            }
+        }
+    }
+    return m_idx;
+}
+
+/* m17_rx_frame.cpp:22-43 */
+static float find_variance(const float *in, int len)
+{
+    float v, mmin, mmax;
+    mmin = fabsf(in[0]);
+    mmax = mmin;
+    for (int i = 1; i < len; i++) {
+        v = fabsf(in[i]);
+        if (v > mmax) mmax = v;
+        else if (v < mmin) mmin = v;
+    }
+    v = (mmax - mmin) / mmax;
+    if (v != v) v = 1.0f;
+    return v;
+}
+
+/* m17_rx_frame.cpp:47-81 */
+void m17o_sync_check(const float *vect, uint8_t *type, uint8_t *votes, float *variance)
+{
+    float sums[6];
+    for (int k = 0; k < 6; k++) sums[k] = vect[0] * t_sframe[k][0];
+    for (int i = 1; i < 8; i++)
+        for (int k = 0; k < 6; k++) sums[k] += vect[i] * t_sframe[k][i];
+    *variance = find_variance(vect, 8);
+    float mmax = 0; int nmax = 0;
+    for (int i = 0; i < 6; i++)
+        if (sums[i] > mmax) { mmax = sums[i]; nmax = i; }
+    *type = (uint8_t)nmax;
+    int v = 0;
+    for (int i = 0; i < 8; i++)
+        if (vect[i] * t_sframe[nmax][i] < 0) v++;
+    *votes = (uint8_t)v;
+}
+
+/* m17_rx_frame.cpp:82-103; the literals 0.3 / 0.5 are doubles there */
+static int sync_ok(uint8_t type, uint8_t votes, float variance, int locked)
+{
+    if (votes > (locked ? 1 : 0)) return 0;
+    if (type == 1 || type == 2 || type == 3 || type == 4)
+        if ((double)variance < (locked ? 0.5 : 0.3)) return 1;
+    return 0;
+}
+
+/* m17_rx_parse.cpp:71-85 */
+static int update_lich(m17o_chan *st, const uint8_t *in)
+{
+    int seq = in[5] >> 5;
+    if (seq < 6) {
+        memcpy(&st->m_lsf[0][seq * 5], in, 5);
+        if (m17o_crc(st->m_lsf[0], 30) == 0) {
+            memcpy(st->m_lsf[1], st->m_lsf[0], 30);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* m17_rx_parse.cpp:34-51.  The reference can run 6 bytes past m_packet[800]
+ * for an (invalid) fn > 25 at EOF; the copy is clamped here. */
+static int parse_packet(m17o_chan *st, const uint8_t *data, uint8_t eof, uint8_t fn)
+{
+    int valid = 0;
+    if (eof) {
+        int n = fn;
+        if (st->m_packet_idx + n > 800) n = 800 - st->m_packet_idx;
+        memcpy(&st->m_packet[st->m_packet_idx], data, (size_t)n);
+        st->m_packet_idx += n;
+        if (m17o_crc(st->m_packet, st->m_packet_idx) == 0) valid = 1;
+        st->m_packet_idx = 0;
+    } else {
+        memcpy(&st->m_packet[fn * 25], data, 25);
+        st->m_packet_idx = fn * 25;
+    }
+    return valid;
+}
+
+/* m17_rx_parse.cpp:185-226 and the three decoders :86-177 */
+void m17o_rx_parse(m17o_chan *st, const float *s, uint8_t type, m17o_rec *r)
+{
+    float sb[384];
+    float so0[488], so1[488];
+    uint8_t bits[244];
+    r->flags |= M17O_F_PARSED;
+    switch (type) {
+    case 0: case 5:
+        st->frame_id_epoch++;                       /* generate_new_frame_id() */
+        break;
+    case 1: {                                       /* decode_link_frame :86-101 */
+        m17o_demap_frame(s, sb);
+        m17o_de_correlate_f(sb, sb, 368);
+        m17o_de_interleave(sb, so0, 368);
+        m17o_de_punc(1, so0, so1, 488);
+        m17o_viterbi_decode(so1, bits, 488);
+        m17o_pack_1_to_8(&bits[1], r->data, 240);
+        if (m17o_crc(st->m_packet, 30) == 0) r->flags |= M17O_F_LSF_GATE;   /* :98 quirk */
+        break; }
+    case 2: {                                       /* decode_stream_frame :105-160 */
+        uint16_t w[4]; int e = 0;
+        m17o_demap_frame(s, sb);
+        m17o_de_correlate_f(sb, sb, 368);
+        m17o_de_interleave(sb, so0, 368);
+        for (int k = 0; k < 4; k++)
+            e += m17o_golay_decode(m17o_hard_decode_24(&so0[24 * k]), &w[k]);
+        st->g_errors += (uint32_t)e;                /* m17_dbase.cpp:79-82 */
+        st->n_frames++;
+        r->golay_errs = (uint8_t)e;
+        /* pack_12_to_8_x4x6, m17_bit_utils.cpp:152-172 */
+        uint32_t ww = ((uint32_t)w[0] << 12) | w[1];
+        r->data[0] = (ww >> 16) & 0xFF; r->data[1] = (ww >> 8) & 0xFF; r->data[2] = ww & 0xFF;
+        ww = ((uint32_t)w[2] << 12) | w[3];
+        r->data[3] = (ww >> 16) & 0xFF; r->data[4] = (ww >> 8) & 0xFF; r->data[5] = ww & 0xFF;
+        if (update_lich(st, r->data)) r->flags |= M17O_F_LICH_OK;
+        m17o_de_punc(2, &so0[96], so1, 296);
+        m17o_viterbi_decode(so1, bits, 296);
+        m17o_pack_1_to_8(&bits[1], &r->data[6], 144);
+        r->fn = (uint16_t)((r->data[6] << 8) | r->data[7]);
+        if (m17o_crc(st->m_lsf[1], 30) == 0) r->flags |= M17O_F_DELIVERED;
+        break; }
+    case 3: {                                       /* decode_packet_frame :161-177 */
+        m17o_demap_frame(s, sb);
+        m17o_de_correlate_f(sb, sb, 368);
+        m17o_de_interleave(sb, so0, 368);
+        m17o_de_punc(3, so0, so1, 420);
+        m17o_viterbi_decode(so1, bits, 420);
+        m17o_pack_1_to_8(&bits[1], r->data, 208);
+        uint8_t eof = r->data[25] >> 7;
+        uint8_t fn = (r->data[25] >> 2) & 0x1F;
+        r->fn = (uint16_t)((eof << 8) | fn);
+        if (parse_packet(st, r->data, eof, fn)) r->flags |= M17O_F_PKT_VALID;
+        break; }
+    case 4:                                         /* decode_bert_frame: empty */
+    default:
+        break;
+    }
+}
+
+static void reset_sync(m17o_chan *st) { for (int i = 0; i < 8; i++) st->m_sync[i] = 0; }
+
+/* m17_dbase.cpp:60-75 */
+static void do_aos(m17o_chan *st) { st->g_errors = 0; st->n_frames = 0; st->in_frame = 1; st->frame_id_epoch++; }
+static void do_los(m17o_chan *st) { st->in_frame = 0; st->frame_id_epoch++; }
+
+static m17o_rec *new_rec(m17o_rec *recs, int cap, int *n, m17o_rec *scratch)
+{
+    m17o_rec *r = (*n < cap) ? &recs[*n] : scratch;
+    memset(r, 0, sizeof *r);
+    (*n)++;
+    return r;
+}
+
+/* m17_rx_frame.cpp:126-177 */
+static int rx_symbols(m17o_chan *st, const float *sym, int len, m17o_rec *recs, int cap, int parse)
+{
+    int n = 0;
+    m17o_rec scratch;
+    for (int i = 0; i < len; i++) {
+        uint8_t type, votes; float var;
+        if (st->m_flock) {
+            st->m_f_sym[st->m_fclk] = sym[i];
+            st->m_fclk = (st->m_fclk + 1) % M17O_FRAME_SYMS;
+            if (st->m_fclk == 0) {
+                m17o_sync_check(st->m_f_sym, &type, &votes, &var);
+                m17o_rec *r = new_rec(recs, cap, &n, &scratch);
+                r->type = type; r->votes = votes; r->variance = var;
+                r->block = st->block_count; r->sym_pos = (uint16_t)i;
+                if (type == 5) {
+                    st->m_flock = 0; reset_sync(st); do_los(st);
+                    r->flags |= M17O_F_EOT;
+                } else if (sync_ok(type, votes, var, 1)) {
+                    r->flags |= M17O_F_SYNC_OK;
+                    if (parse) m17o_rx_parse(st, st->m_f_sym, type, r);
+                    st->m_frame_errors = 0;
+                } else {
+                    st->m_frame_errors++;
+                    if (st->m_frame_errors > 5) {
+                        st->m_flock = 0; reset_sync(st); do_los(st);
+                        r->flags |= M17O_F_LOST;
+                    } else if (parse) {
+                        m17o_rx_parse(st, st->m_f_sym, type, r);
+                    }
+                }
+                r->frame_errors = (uint8_t)st->m_frame_errors;
+            }
+        } else {
+            for (int k = 0; k < 7; k++) st->m_sync[k] = st->m_sync[k + 1];
+            st->m_sync[7] = sym[i];
+            m17o_sync_check(st->m_sync, &type, &votes, &var);
+            if (sync_ok(type, votes, var, 0)) {
+                for (int k = 0; k < 8; k++) st->m_f_sym[k] = st->m_sync[k];
+                st->m_fclk = 8;
+                st->m_frame_errors = 0;
+                st->m_flock = 1;
+                do_aos(st);
+                m17o_rec *r = new_rec(recs, cap, &n, &scratch);
+                r->type = type; r->votes = votes; r->variance = var;
+                r->block = st->block_count; r->sym_pos = (uint16_t)i;
+                r->flags = M17O_F_AOS;
+            }
+        }
+    }
+    return n;
+}
+
+int m17o_rx_symbols(m17o_chan *st, const float *sym, int n, m17o_rec *recs, int cap)
+{
+    return rx_symbols(st, sym, n, recs, cap, 1);
+}
+
+/* m17_dsp.cpp:461-476 (AFC branch :468 not taken: radio.cpp:8 default off) */
+static int dsp_rx(m17o_chan *st, const int16_t *iq, m17o_rec *recs, int cap,
+                  float *syms, int *nsym, int parse)
+{
+    float tempd[M17O_DISC_OUT];
+    float tempc[M17O_BLOCK_SAMPLES / 2];
+    m17o_frontend(st, iq, tempd, NULL, NULL);
+    int n = m17o_rx_sync_samples(st, tempd, tempc, M17O_DISC_OUT);
+    if (syms) memcpy(syms, tempc, sizeof(float) * (size_t)(n > 0 ? n : 0));
+    if (nsym) *nsym = n;
+    int k = rx_symbols(st, tempc, n, recs, cap, parse);
+    st->block_count++;
+    return k;
+}
+
+int m17o_dsp_rx(m17o_chan *st, const int16_t *iq, m17o_rec *recs, int cap, float *syms, int *nsym)
+{
+    return dsp_rx(st, iq, recs, cap, syms, nsym, 1);
+}
+
+int m17o_rx_blocks(m17o_chan *st, int C, int nblk, const int16_t *iq,
+                   m17o_rec *recs, int cap, int32_t *counts,
+                   float *syms, int32_t *nsyms, int mode, int nthreads)
+{
+    const size_t blk = (size_t)M17O_BLOCK_SAMPLES * 2;
+    const size_t symstride = (size_t)nblk * 193 + 8;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int c = 0; c < C; c++) {
+        int n = 0, ns = 0;
+        for (int b = 0; b < nblk; b++) {
+            int k = 0;
+            int at = n < cap ? n : cap;
+            n += dsp_rx(&st[c], iq + ((size_t)c * nblk + b) * blk,
+                        recs ? recs + (size_t)c * cap + at : NULL, recs ? cap - at : 0,
+                        syms ? syms + (size_t)c * symstride + ns : NULL, &k, mode);
+            if (k < 0) k = 0;
+            if (nsyms) nsyms[(size_t)c * nblk + b] = k;
+            ns += k;
+        }
+        if (counts) counts[c] = n;
+    }
+    return 0;
+}

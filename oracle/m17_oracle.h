@@ -1,0 +1,144 @@
+/*
+ * m17_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A from-scratch plain-C restatement of the receive hot path of G4GUO/m17_sdr
+ * (reference tree m17gismo/, tag v1).  Every function cites the reference
+ * file:line whose arithmetic it follows.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; the product path
+ * (m17_sdr_amd/) never links, imports or calls it.
+ *
+ * PARITY PIN STATUS (see DESIGN.md "Oracle"):
+ *   - codec primitives (CRC, Golay, interleaver, de-randomiser, puncture,
+ *     convolutional code/Viterbi round trip, callsign, RRC tap design):
+ *     pinned by the known-answer values SURVEY.md section 8(c) recorded from the
+ *     compiled reference, and by the M17 specification constants.
+ *   - streaming DSP stages (a3..a12: int16->float, limiter, discriminator,
+ *     timing loop, framer): PARITY UNPINNED.  The reference cannot be built in
+ *     this image without writing a stand-in for the absent codec2.h (every
+ *     reference TU includes it through m17defines.h:5) and for its HAL/GUI
+ *     translation units, which the build rules forbid; only behavioural KATs
+ *     (loop-back lock / delivery counts from SURVEY.md 8c) are available.
+ */
+#ifndef M17_ORACLE_H
+#define M17_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M17O_BLOCK_SAMPLES 1920   /* m17defines.h:17 N_SAMPLES */
+#define M17O_DISC_OUT       384   /* N_SAMPLES/5, m17_dsp.cpp:463 */
+#define M17O_FRAME_SYMS     192   /* m17defines.h:66 */
+#define M17O_NF              40   /* m17_rx_sync.cpp:3 */
+#define M17O_FN              31   /* m17_rx_sync.cpp:4 */
+#define M17O_SYM_MAX        200   /* >= 193 symbols per block */
+
+/* record flags (identical numbering to include/m17gpu.h by convention) */
+#define M17O_F_SYNC_OK    0x0001  /* m17_locked_sync_check passed */
+#define M17O_F_PARSED     0x0002  /* m17_rx_parse was called */
+#define M17O_F_LICH_OK    0x0004  /* update_lich: CRC(m_lsf[0])==0, good copy refreshed */
+#define M17O_F_DELIVERED  0x0008  /* stream payload handed to the sink */
+#define M17O_F_EOT        0x0010  /* EOT sync -> unlock */
+#define M17O_F_LOST       0x0020  /* > N_FERROR bad syncs -> unlock */
+#define M17O_F_LSF_GATE   0x0040  /* decode_link_frame CRC gate (m_packet quirk) open */
+#define M17O_F_PKT_VALID  0x0080  /* parse_packet: CRC==0 at EOF */
+#define M17O_F_AOS        0x0100  /* lock acquired (not a frame) */
+
+typedef struct {
+    uint8_t  type;          /* sync type 0..5 (m17_rx_frame.cpp:5-12 row) */
+    uint8_t  votes;         /* sign mismatches vs winning template */
+    uint8_t  golay_errs;    /* stream: sum of the four Golay weights */
+    uint8_t  frame_errors;  /* m_frame_errors after this frame */
+    uint16_t flags;
+    uint16_t fn;            /* stream: FN; packet: (eof<<8)|fn */
+    float    variance;
+    uint32_t block;         /* block index since reset in which it completed */
+    uint16_t sym_pos;       /* index of the completing symbol inside the block */
+    uint16_t rsv0;
+    uint8_t  data[32];      /* LSF: 30 B; stream: lich[6]+pld[18]; packet: 26 B */
+    uint8_t  rsv[12];
+} m17o_rec;                 /* 64 bytes */
+
+typedef struct {
+    /* front end, m17_dsp.cpp:195-196 */
+    int32_t disc_count;
+    float   z0re, z0im, z1re, z1im;
+    /* timing loop, m17_rx_sync.cpp:6-11,43,78 */
+    int32_t m_clk, m_thr, m_index;
+    float   sum, dif;
+    float   m_buff[M17O_FN];
+    /* framer, m17_rx_frame.cpp:14-18,104 */
+    int32_t m_flock, m_fclk, m_frame_errors;
+    float   m_sync[8];
+    float   m_f_sym[M17O_FRAME_SYMS];
+    /* parser, m17_rx_parse.cpp:5-8 */
+    uint8_t m_lsf[2][30];
+    uint8_t pad0[4];
+    uint8_t m_packet[800];
+    int32_t m_packet_idx;
+    /* bookkeeping mirrored from m17_dbase.cpp:60-82 */
+    uint32_t g_errors, n_frames, in_frame, frame_id_epoch;
+    uint32_t block_count;
+} m17o_chan;
+
+/* ---- init / tables ---- */
+void m17o_init(void);                                  /* main.cpp:110-118 order */
+void m17o_chan_reset(m17o_chan *st);
+const float *m17o_tab_mf(void);                        /* [40][31] m17_rx_sync.cpp:12 */
+const float *m17o_tab_md(void);                        /* [40][31] m17_rx_sync.cpp:13 */
+const uint16_t *m17o_tab_golay_enc(void);              /* [4096] */
+const uint16_t *m17o_tab_golay_err(void);              /* [4096] */
+const uint8_t *m17o_tab_derand(void);                  /* [368] */
+const uint16_t *m17o_tab_crc(void);                    /* [256] */
+
+/* ---- primitives ---- */
+void     m17o_build_rrc_filter(float *f, float rolloff, int ntaps, int sps);
+void     m17o_set_filter_gain(float *f, float gain, int stride, int ntaps);
+uint16_t m17o_crc(const uint8_t *in, int len);
+uint32_t m17o_golay_encode(uint16_t data);
+int      m17o_golay_decode(uint32_t word, uint16_t *odata);
+int      m17o_conv_encode_8(const uint8_t *in, uint8_t *out, int len);
+int      m17o_conv_encode_1(const uint8_t *in, uint8_t *out, int len);
+int      m17o_punc(int which, const uint8_t *in, uint8_t *out, int len);
+int      m17o_de_punc(int which, const float *in, float *out, int len);
+void     m17o_interleave_u8(const uint8_t *in, uint8_t *out, int len);
+void     m17o_de_interleave(const float *in, float *out, int len);
+void     m17o_de_correlate_u8(const uint8_t *in, uint8_t *out, int len);
+void     m17o_de_correlate_f(const float *in, float *out, int len);
+int      m17o_viterbi_decode(const float *in, uint8_t *out, int len);
+uint32_t m17o_hard_decode_24(const float *in);
+int      m17o_pack_1_to_8(const uint8_t *in, uint8_t *out, int len);
+void     m17o_demap_frame(const float *in, float *out);
+uint64_t m17o_encode_call(const char *call);
+void     m17o_decode_call(uint64_t w, char *call);
+void     m17o_prbs9(uint8_t *out, int len);
+void     m17o_sync_check(const float *v, uint8_t *type, uint8_t *votes, float *variance);
+
+/* ---- streaming stages (one channel) ---- */
+/* a3+a5+a6: int16 IQ[1920*2] -> d[384] (DC removed); raw (before DC removal)
+ * and offset optionally returned */
+void m17o_frontend(m17o_chan *st, const int16_t *iq, float *d, float *d_raw, float *offset);
+/* a9: returns number of symbols (191..193) */
+int  m17o_rx_sync_samples(m17o_chan *st, const float *in, float *out, int len);
+/* a12+a13..a25: symbols -> records; returns number of records appended */
+int  m17o_rx_symbols(m17o_chan *st, const float *sym, int n, m17o_rec *recs, int cap);
+/* frame decode alone: float s[192] + type -> record fields (stateful LICH) */
+void m17o_rx_parse(m17o_chan *st, const float *s, uint8_t type, m17o_rec *r);
+/* a2: whole block; returns records appended; syms/nsym optional outputs */
+int  m17o_dsp_rx(m17o_chan *st, const int16_t *iq, m17o_rec *recs, int cap,
+                 float *syms, int *nsym);
+
+/* ---- batch driver for the CPU baseline (OpenMP over channels) ----
+ * iq: [C][nblk][1920][2]; recs: [C][cap]; counts: [C]; syms: per channel a
+ * contiguous symbol stream [C][nblk*193+8] or NULL; nsyms: per-block symbol
+ * counts [C][nblk] or NULL; mode 0 = front end only (a2 without parse), 1 = full chain */
+int  m17o_rx_blocks(m17o_chan *st, int C, int nblk, const int16_t *iq,
+                    m17o_rec *recs, int cap, int32_t *counts,
+                    float *syms, int32_t *nsyms, int mode, int nthreads);
+int  m17o_sizeof_chan(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
