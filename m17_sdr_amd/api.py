@@ -1,0 +1,176 @@
+"""Host-side handle around the C-ABI: owns an m17gpu context, passes torch
+tensors' device pointers and the current HIP stream through.  Mirrors the
+reference call structure: Receiver.rx_blocks == batched m17_dsp_rx
+(m17_dsp.cpp:461-476), Receiver.viterbi_decode == m17_viterbi_decode
+(m17_conv.cpp:148-168), and so on.  Errors from the library raise RuntimeError;
+nothing here falls back to a CPU implementation."""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+
+
+def lib():
+    return _lib.load()
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().m17gpu_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Receiver:
+    """C independent 48 kHz M17 channels resident on one GPU."""
+
+    def __init__(self, n_channels, max_blocks, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("m17_sdr_amd.Receiver needs a HIP device (no CPU fallback)")
+        self.C, self.max_blocks, self.device = int(n_channels), int(max_blocks), int(device)
+        self.rec_cap_max = 2 * self.max_blocks + 2
+        torch.cuda.set_device(self.device)
+        torch.zeros(1, device=f"cuda:{self.device}")          # make sure torch's HIP context exists first
+        self._ctx = C.c_void_p()
+        _check(lib().m17gpu_create(C.byref(self._ctx), self.C, self.max_blocks, self.device), "m17gpu_create")
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            lib().m17gpu_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        _check(lib().m17gpu_reset(self._ctx, _stream()), "m17gpu_reset")
+
+    # ---- hot path -------------------------------------------------------
+    def alloc_outputs(self, nblk, rec_cap=None, want_syms=False):
+        import torch
+        dev = f"cuda:{self.device}"
+        rec_cap = self.rec_cap_max if rec_cap is None else rec_cap
+        out = {
+            "recs": torch.zeros((self.C, rec_cap, 64), dtype=torch.uint8, device=dev),
+            "counts": torch.zeros((self.C,), dtype=torch.int32, device=dev),
+            "syms": None, "nsyms": None, "rec_cap": rec_cap,
+        }
+        if want_syms:
+            out["syms"] = torch.zeros((self.C, _lib.sym_stride(nblk)), dtype=torch.float32, device=dev)
+            out["nsyms"] = torch.zeros((self.C, nblk), dtype=torch.int32, device=dev)
+        return out
+
+    def rx_blocks(self, iq, mode, out):
+        """iq: int16 cuda tensor [C, nblk, 1920, 2]; out: dict from alloc_outputs."""
+        assert iq.is_cuda and iq.dtype.__str__() == "torch.int16" and iq.is_contiguous()
+        assert iq.shape[0] == self.C and tuple(iq.shape[2:]) == (1920, 2), iq.shape
+        nblk = int(iq.shape[1])
+        _check(lib().m17gpu_rx_blocks(self._ctx, _ptr(iq), nblk, int(mode), _ptr(out["recs"]),
+                                      int(out["rec_cap"]), _ptr(out["counts"]), _ptr(out["syms"]),
+                                      _ptr(out["nsyms"]), _stream()), "m17gpu_rx_blocks")
+        return out
+
+    # ---- stage entry points ----------------------------------------------
+    def frontend(self, iq):
+        import torch
+        nblk = int(iq.shape[1])
+        disc = torch.empty((self.C, nblk, 384), dtype=torch.float32, device=iq.device)
+        offs = torch.empty((self.C, nblk), dtype=torch.float32, device=iq.device)
+        _check(lib().m17gpu_frontend(self._ctx, _ptr(iq), nblk, _ptr(disc), _ptr(offs), _stream()),
+               "m17gpu_frontend")
+        return disc, offs
+
+    def sync_frame(self, disc, out):
+        nblk = int(disc.shape[1])
+        _check(lib().m17gpu_sync_frame(self._ctx, _ptr(disc), nblk, _ptr(out["recs"]), int(out["rec_cap"]),
+                                       _ptr(out["counts"]), _ptr(out["syms"]), _ptr(out["nsyms"]), _stream()),
+               "m17gpu_sync_frame")
+        return out
+
+    def viterbi_decode(self, soft):
+        import torch
+        n, length = int(soft.shape[0]), int(soft.shape[1])
+        bits = torch.empty((n, length // 2), dtype=torch.uint8, device=soft.device)
+        _check(lib().m17gpu_viterbi_decode(self._ctx, _ptr(soft), _ptr(bits), length, n, _stream()),
+               "m17gpu_viterbi_decode")
+        return bits
+
+    def demap_frame(self, sym):
+        import torch
+        n = int(sym.shape[0])
+        soft = torch.empty((n, 368), dtype=torch.float32, device=sym.device)
+        _check(lib().m17gpu_demap_frame(self._ctx, _ptr(sym), _ptr(soft), n, _stream()), "m17gpu_demap_frame")
+        return soft
+
+    def decode_frames(self, sym, types):
+        import torch
+        n = int(sym.shape[0])
+        recs = torch.zeros((n, 64), dtype=torch.uint8, device=sym.device)
+        _check(lib().m17gpu_decode_frames(self._ctx, _ptr(sym), _ptr(types), _ptr(recs), n, _stream()),
+               "m17gpu_decode_frames")
+        return recs
+
+    def golay_decode(self, words):
+        import torch
+        n = int(words.shape[0])
+        out = torch.empty((n,), dtype=torch.int16, device=words.device)
+        _check(lib().m17gpu_golay_decode(self._ctx, _ptr(words), _ptr(out), n, _stream()), "m17gpu_golay_decode")
+        return out
+
+    # ---- state -------------------------------------------------------------
+    def lsf(self):
+        a = np.zeros((self.C, 2, 30), np.uint8)
+        _check(lib().m17gpu_get_lsf(self._ctx, a.ctypes.data_as(C.c_void_p)), "m17gpu_get_lsf")
+        return a
+
+    def counters(self):
+        a = np.zeros((self.C, 4), np.uint32)
+        _check(lib().m17gpu_get_counters(self._ctx, a.ctypes.data_as(C.c_void_p)), "m17gpu_get_counters")
+        return a
+
+    def lock(self):
+        a = np.zeros((self.C,), np.uint8)
+        _check(lib().m17gpu_get_lock(self._ctx, a.ctypes.data_as(C.c_void_p)), "m17gpu_get_lock")
+        return a
+
+
+def generate_channel(seed, nblk, n_stream_frames=40, delay=0, ebn0_db=200.0, packet_mode=0, max_frames=None):
+    """Host signal source for one channel: (iq[nblk,1920,2] int16, lsf[30], payloads[n,16], n)."""
+    max_frames = max_frames or (nblk + 2)
+    iq = np.zeros((nblk, 1920, 2), np.int16)
+    lsf = np.zeros(30, np.uint8)
+    pl = np.zeros((max_frames, 16), np.uint8)
+    p = _lib.GenParams(seed, n_stream_frames, delay, ebn0_db, packet_mode)
+    n = lib().m17gen_channel(C.byref(p), nblk, iq.ctypes.data_as(C.c_void_p), lsf.ctypes.data_as(C.c_void_p),
+                             pl.ctypes.data_as(C.c_void_p), max_frames)
+    if n < 0:
+        raise RuntimeError(f"m17gen_channel failed ({n})")
+    return iq, lsf, pl, n
+
+
+def generate_batch(n_channels, nblk, n_stream_frames=40, ebn0_db=200.0, base_seed=0x4D313700,
+                   first_channel=0, packet_mode=0, nthreads=8, out=None):
+    """Host signal source for C channels: dict(iq[C,nblk,1920,2], lsf[C,30], payload[C,F,16], nframes[C])."""
+    max_frames = nblk + 2
+    iq = out if out is not None else np.zeros((n_channels, nblk, 1920, 2), np.int16)
+    lsf = np.zeros((n_channels, 30), np.uint8)
+    pl = np.zeros((n_channels, max_frames, 16), np.uint8)
+    nf = np.zeros((n_channels,), np.int32)
+    rc = lib().m17gen_batch(n_channels, base_seed, first_channel, nblk, n_stream_frames, ebn0_db, packet_mode,
+                            iq.ctypes.data_as(C.c_void_p), lsf.ctypes.data_as(C.c_void_p),
+                            pl.ctypes.data_as(C.c_void_p), max_frames, nf.ctypes.data_as(C.c_void_p), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"m17gen_batch failed ({rc})")
+    return {"iq": iq, "lsf": lsf, "payload": pl, "nframes": nf}

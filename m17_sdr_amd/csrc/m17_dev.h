@@ -1,0 +1,73 @@
+// m17_dev.h -- device-side data layout shared by the kernels and the C-ABI host code.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+
+namespace m17dev {
+
+constexpr int kBlockSamples = 1920;   // m17defines.h:17
+constexpr int kDiscOut      = 384;    // m17_dsp.cpp:463
+constexpr int kFrameSyms    = 192;    // m17defines.h:66
+constexpr int kSoftBits     = 368;
+constexpr int kPhases       = 40;     // m17_rx_sync.cpp:3
+constexpr int kTaps         = 31;     // m17_rx_sync.cpp:4
+
+#define M17_SYM_STRIDE(nblk) ((size_t)(nblk) * 193 + 8)
+
+#define M17_F_SYNC_OK    0x0001u
+#define M17_F_PARSED     0x0002u
+#define M17_F_LICH_OK    0x0004u
+#define M17_F_DELIVERED  0x0008u
+#define M17_F_EOT        0x0010u
+#define M17_F_LOST       0x0020u
+#define M17_F_LSF_GATE   0x0040u
+#define M17_F_PKT_VALID  0x0080u
+#define M17_F_AOS        0x0100u
+
+// binary-identical to m17gpu_rec (include/m17gpu.h)
+struct m17gpu_rec_dev {
+    uint8_t  type, votes, golay_errs, frame_errors;
+    uint16_t flags, fn;
+    float    variance;
+    uint32_t block;
+    uint16_t sym_pos, rsv0;
+    uint8_t  data[32];
+    uint8_t  rsv[12];
+};
+static_assert(sizeof(m17gpu_rec_dev) == 64, "record must be 64 bytes");
+
+// Per-channel state in HBM: the reference's file-static variables of one
+// receiver instance (SURVEY.md section 5 "stream continuity"), 1,920 bytes.
+struct ChanState {
+    // discriminator memory z[0], z[1]                      m17_dsp.cpp:196
+    float    z0re, z0im, z1re, z1im;
+    // timing loop                                           m17_rx_sync.cpp:6-9,78
+    int32_t  clk, thr, index;
+    float    sum, dif;
+    // framer                                                m17_rx_frame.cpp:16-18
+    int32_t  flock, fclk, ferr;
+    uint32_t block_count;
+    // m17_dbase.cpp:60-82 mirrors
+    uint32_t g_errors, n_frames, in_frame, frame_id_epoch;
+    int32_t  packet_idx;                                  // m17_rx_parse.cpp:7
+    int32_t  pad[14];
+    float    buff[32];                                    // m_buff[31]           m17_rx_sync.cpp:11
+    float    sync[8];                                     // m_sync               m17_rx_frame.cpp:104
+    float    fsym[kFrameSyms];                            // m_f_sym              m17_rx_frame.cpp:14
+    uint8_t  lsf[2][32];                                  // m_lsf[2][30]         m17_rx_parse.cpp:5
+    uint8_t  packet[800];                                 // m_packet             m17_rx_parse.cpp:6
+};
+static_assert(sizeof(ChanState) == 1920, "ChanState layout");
+
+// constant tables (built on the host by m17::tables())
+struct DevTables {
+    float    mf[kPhases][32];        // matched filter taps, 31 used
+    float    md[kPhases][32];        // derivative filter taps
+    int16_t  gather[4][488];         // -1 erasure, else src | 0x4000 when negated
+    int16_t  lich[96];
+    int16_t  glen[4];
+    uint8_t  bm_even[16], bm_odd[16];
+    uint16_t crc[256];
+};
+
+} // namespace m17dev

@@ -1,0 +1,810 @@
+// m17_kernels.hip -- CDNA4 (gfx950) kernels of the batched M17 receive chain.
+//
+// Data-parallel restatement of the reference's single-channel, file-static
+// receive path.  Four kernels per call:
+//
+//   k_frontend    a3+a5+a6   int16 IQ -> limiter -> discriminator -> /5 -> DC sum
+//                 one LANE per (channel, block): the 1920-term DC sum is a strict
+//                 sequential fp32 chain, so each lane owns one chain; the IQ tile
+//                 is staged through LDS so HBM sees 160-byte row segments and the
+//                 per-lane reads are conflict-free ds_read_b128.
+//   k_sync_frame  a9+a11+a12 timing recovery + sync correlator + framer
+//                 one WAVE per channel, blocks in order: 64 lanes evaluate 64
+//                 consecutive symbol instants of the polyphase matched/derivative
+//                 FIR speculatively under the current phase; the vote counter is a
+//                 ballot/popcount prefix, the first threshold crossing truncates
+//                 the speculation.  Sync-word hunting correlates 64 window
+//                 positions at once.
+//   k_decode      a14..a24   demap, fused de-randomise/de-interleave/de-puncture
+//                 gather, Viterbi with one trellis state per lane (16 lanes per
+//                 frame, ds_bpermute butterflies), Golay, packers.
+//   k_lsf         a25 etc.   per-channel in-order LICH/LSF/packet bookkeeping.
+//
+// Numeric contract: IEEE binary32, no FMA contraction, no
+// re-association, correctly rounded sqrt/divide; the double-promoted
+// expressions of the reference are evaluated in fp64.  Build with
+// -ffp-contract=off and WITHOUT -ffast-math.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "m17_dev.h"
+
+#pragma clang fp contract(off)
+
+namespace m17dev {
+
+__constant__ DevTables c_tab;
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ float bcast_lane(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ int bcast_lane_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// dsp_short_to_float (m17_dsp.cpp:136-141): (float)((double)x * 0.00003)
+__device__ __forceinline__ float s16_to_float(int x) { return (float)((double)x * 0.00003); }
+
+// dsp_limit (m17_dsp.cpp:412-419): m = sqrtf(re^2+im^2); g = (float)(1.0/m).
+// (float)(1.0/(double)m) == correctly rounded 1.0f/m (double rounding is
+// innocuous for division at 53 >= 2*24+2 bits), so fp32 IEEE divide is used.
+__device__ __forceinline__ void limit(float &re, float &im)
+{
+    const float m = __builtin_sqrtf(re * re + im * im);   // IEEE-correct under -fhip-fp32-correctly-rounded-divide-sqrt
+    const float g = 1.0f / m;
+    re = re * g;
+    im = im * g;
+}
+
+// ---------------------------------------------------------------------------
+// k_frontend
+// ---------------------------------------------------------------------------
+constexpr int FE_CHUNK   = 20;               // samples per LDS chunk: lcm(4 samples/uint4, /5 decimation)
+constexpr int FE_STRIDE  = FE_CHUNK;         // dwords per LDS row; 20 = 4*5 (odd multiple of 4): the 16
+                                             // lanes of a ds_read_b128 group tile all 64 banks
+constexpr int FE_NCHUNK  = kBlockSamples / FE_CHUNK;   // 96
+constexpr int FE_LOADS   = FE_CHUNK / 4;     // uint4 loads per lane per chunk = 5
+constexpr int FE_WAVES   = 4;
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS traffic of one wave executes in order; this only pins the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64 * FE_WAVES)
+void k_frontend(const uint4 *__restrict__ iq,        // [total][480] uint4 (4 IQ samples each)
+                ChanState *__restrict__ st,
+                float *__restrict__ disc_raw,        // [total][384]
+                float *__restrict__ offs,            // [total]
+                int nblk, int total, int update_state)
+{
+    // per-wave double-buffered tile: [buf][row = lane's (channel,block)][20 samples]
+    __shared__ __attribute__((aligned(16))) uint32_t tile[FE_WAVES][2][64 * FE_STRIDE];
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int cb0 = ((int)blockIdx.x * FE_WAVES + wave) * 64;
+    if (cb0 >= total) return;                            // no block-level barrier below
+    const bool valid = (cb0 + lane) < total;
+    const int cb = valid ? cb0 + lane : total - 1;
+    const int chan = cb / nblk, blk = cb - chan * nblk;
+
+    // discriminator memory z[0], z[1] (m17_dsp.cpp:196): from channel state for
+    // the first block of the call, otherwise the limited last two samples of the
+    // preceding block, which sit right in front of this row in the IQ array.
+    float z0re, z0im, z1re, z1im;
+    if (blk == 0) {
+        z0re = st[chan].z0re; z0im = st[chan].z0im; z1re = st[chan].z1re; z1im = st[chan].z1im;
+    } else {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(iq) + (size_t)cb * kBlockSamples;
+        const uint32_t a = p[-2], b = p[-1];
+        z1re = s16_to_float((int)(short)(a & 0xFFFF)); z1im = s16_to_float((int)a >> 16);
+        z0re = s16_to_float((int)(short)(b & 0xFFFF)); z0im = s16_to_float((int)b >> 16);
+        limit(z1re, z1im);
+        limit(z0re, z0im);
+    }
+
+    // staging slots of this lane: uint4 number (j*64+lane) of the chunk tile, i.e.
+    // 5 consecutive lanes fetch one row's 80-byte segment
+    uint4 stage[FE_LOADS];
+    const uint4 *gsrc[FE_LOADS];
+    int loff[FE_LOADS];
+#pragma unroll
+    for (int j = 0; j < FE_LOADS; ++j) {
+        const int idx = j * 64 + lane;
+        const int r = idx / FE_LOADS, c4 = idx - r * FE_LOADS;
+        int row = cb0 + r; row = row < total ? row : total - 1;
+        gsrc[j] = iq + (size_t)row * (kBlockSamples / 4) + c4;
+        loff[j] = r * FE_STRIDE + c4 * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < FE_LOADS; ++j) stage[j] = gsrc[j][0];
+#pragma unroll
+    for (int j = 0; j < FE_LOADS; ++j) *reinterpret_cast<uint4 *>(&tile[wave][0][loff[j]]) = stage[j];
+    wave_lds_sync();
+
+    float offset = 0.0f;
+    float *dst = disc_raw + (size_t)cb * kDiscOut;
+    for (int chunk = 0; chunk < FE_NCHUNK; ++chunk) {
+        const uint32_t *cur = tile[wave][chunk & 1];
+        uint32_t *nxt = tile[wave][(chunk + 1) & 1];
+        // prefetch the next chunk (the last iteration re-reads its own chunk: no branch,
+        // the register array stays out of scratch)
+        const int nx = (chunk + 1 < FE_NCHUNK) ? chunk + 1 : chunk;
+#pragma unroll
+        for (int j = 0; j < FE_LOADS; ++j) stage[j] = gsrc[j][nx * FE_LOADS];
+        float o[FE_CHUNK / 5];
+#pragma unroll
+        for (int q = 0; q < FE_CHUNK / 4; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&cur[lane * FE_STRIDE + q * 4]);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int s = q * 4 + e;
+                float re = s16_to_float((int)(short)(w[e] & 0xFFFF));
+                float im = s16_to_float((int)w[e] >> 16);
+                limit(re, im);
+                // dsp_arctan_disc2 (m17_dsp.cpp:194-222)
+                const float a = z0im * (re - z1re);
+                const float b = z0re * (im - z1im);
+                const float u = b - a;
+                z1re = z0re; z1im = z0im; z0re = re; z0im = im;
+                const float uh = u * 0.5f;
+                if (s % 5 == 4) o[s / 5] = uh;       // count%5==0 pick; 1920%5==0 keeps the phase
+                offset += uh;                         // strictly sequential DC sum
+            }
+        }
+        if (valid)
+            *reinterpret_cast<float4 *>(dst + chunk * (FE_CHUNK / 5)) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int j = 0; j < FE_LOADS; ++j) *reinterpret_cast<uint4 *>(&nxt[loff[j]]) = stage[j];
+        wave_lds_sync();
+    }
+    if (valid) {
+        offs[cb] = offset / (float)kBlockSamples;     // offset/len (m17_dsp.cpp:213)
+        if (update_state && blk == nblk - 1) {
+            st[chan].z0re = z0re; st[chan].z0im = z0im; st[chan].z1re = z1re; st[chan].z1im = z1im;
+        }
+    }
+}
+
+// out[i] -= offset (m17_dsp.cpp:217-219) for the stand-alone front-end entry point
+__global__ void k_dc_remove(float *__restrict__ disc, const float *__restrict__ offs, int total)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < total * kDiscOut) disc[i] = disc[i] - offs[i / kDiscOut];
+}
+
+// ---------------------------------------------------------------------------
+// sync correlator (m17_rx_frame.cpp:47-81 + :22-43)
+// ---------------------------------------------------------------------------
+struct SyncResult { int type; int votes; float variance; };
+
+__device__ __forceinline__ SyncResult sync_check(const float v[8])
+{
+    // bit i set = template symbol i is -1 (sframe, m17_rx_frame.cpp:5-12);
+    // multiplying by +-1.0f is exact, so the running sums use add / subtract
+    constexpr unsigned neg[6] = {0xAA, 0xB0, 0x4F, 0xF2, 0x0D, 0x40};
+    float sums[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float s = (neg[k] & 1u) ? -v[0] : v[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s = (neg[k] >> i & 1u) ? s - v[i] : s + v[i];
+        sums[k] = s;
+    }
+    float mmin = fabsf(v[0]), mmax = mmin;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        const float a = fabsf(v[i]);
+        if (a > mmax) mmax = a;
+        else if (a < mmin) mmin = a;
+    }
+    float var = (mmax - mmin) / mmax;
+    if (var != var) var = 1.0f;
+    float best = 0.0f; int nmax = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if (sums[k] > best) { best = sums[k]; nmax = k; }
+    unsigned nm = neg[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) nm = (nmax == k) ? neg[k] : nm;
+    int votes = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool bad = (nm >> i & 1u) ? (v[i] > 0.0f) : (v[i] < 0.0f);
+        votes += bad ? 1 : 0;
+    }
+    SyncResult r; r.type = nmax; r.votes = votes; r.variance = var;
+    return r;
+}
+
+// m17_unlocked_sync_check / m17_locked_sync_check (m17_rx_frame.cpp:82-103).
+// `variance < 0.3` compares against a double literal: (double)v < 0.3 <=> v < 0.3f
+// because 0.3f is the float nearest to and above 0.3; 0.5 is exact.
+__device__ __forceinline__ bool sync_accept(const SyncResult &r, bool locked)
+{
+    if (r.votes > (locked ? 1 : 0)) return false;
+    if (r.type >= 1 && r.type <= 4) return (double)r.variance < (locked ? 0.5 : 0.3);
+    return false;
+}
+
+// ---------------------------------------------------------------------------
+// k_sync_frame: one wave per channel
+// ---------------------------------------------------------------------------
+constexpr int SF_WAVES = 4;
+
+struct SfShared {
+    float x[kTaps - 1 + kDiscOut + 2];     // delay-line history (30) + this block's 384 inputs
+    float out[208];                        // m17_rx_sync_samples output of this block
+    float h[8 + 208];                      // m_sync (8) followed by the block's symbols
+    float f[kFrameSyms];                   // m_f_sym
+};
+
+__device__ __forceinline__ void emit_record(m17gpu_rec_dev *recs, int rec_cap, int idx,
+                                            uint32_t w0, uint32_t w1, float var, uint32_t block, uint32_t sympos)
+{
+    if (idx >= rec_cap) return;
+    uint32_t *r = reinterpret_cast<uint32_t *>(&recs[idx]);
+    const int lane = lane_id();
+    if (lane < 16) {
+        uint32_t v = 0;
+        if (lane == 0) v = w0;
+        if (lane == 1) v = w1;
+        if (lane == 2) v = __float_as_uint(var);
+        if (lane == 3) v = block;
+        if (lane == 4) v = sympos;
+        r[lane] = v;
+    }
+}
+
+__global__ __launch_bounds__(64 * SF_WAVES)
+void k_sync_frame(const float *__restrict__ disc,     // [C][nblk][384]
+                  const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
+                  ChanState *__restrict__ st, int C, int nblk, int mode,
+                  m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
+                  float *__restrict__ syms, int32_t *__restrict__ nsyms,
+                  float *__restrict__ fsym,            // [C][rec_cap][192] frames to decode (mode 1)
+                  int32_t *__restrict__ work, int32_t *__restrict__ nwork)
+{
+    __shared__ SfShared sh_all[SF_WAVES];
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int chan = (int)blockIdx.x * SF_WAVES + wave;
+    if (chan >= C) return;                              // whole wave exits; no block-level barrier below
+    SfShared &sh = sh_all[wave];
+    ChanState &cs = st[chan];
+    m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
+
+    // ---- load state (wave-uniform scalars + LDS arrays)
+    int clk = uni(cs.clk), thr = uni(cs.thr), index = uni(cs.index);
+    float sum = unif(cs.sum), dif = unif(cs.dif);
+    int flock = uni(cs.flock), fclk = uni(cs.fclk), ferr = uni(cs.ferr);
+    uint32_t block_count = (uint32_t)uni((int)cs.block_count);
+    if (lane < kTaps - 1) sh.x[lane] = cs.buff[lane + 1];       // last 30 inputs
+    if (lane < 8) sh.h[lane] = cs.sync[lane];
+    for (int q = lane; q < kFrameSyms; q += 64) sh.f[q] = cs.fsym[q];
+    int nrec = 0;
+    size_t sym_base = (size_t)chan * M17_SYM_STRIDE(nblk);
+    int sym_total = 0;
+
+    for (int b = 0; b < nblk; ++b) {
+        // ---- stage the block's discriminator samples, DC removed (m17_dsp.cpp:217-219)
+        const float *src = disc + ((size_t)chan * nblk + b) * kDiscOut;
+        const float off = offs ? offs[(size_t)chan * nblk + b] : 0.0f;
+        for (int q = lane; q < kDiscOut; q += 64) {
+            const float v = src[q];
+            sh.x[kTaps - 1 + q] = offs ? (v - off) : v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        // ---- timing recovery (m17_rx_sync.cpp:77-99), x[i .. i+30] is the delay line at input i
+        const int thresh = flock ? 80 : 10;
+        int p = 0, m_idx = 0;
+        while (p < kDiscOut) {
+            if (clk == 1) {
+                // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72)
+                clk = 0;
+                float d = (sum < 0.0f) ? -dif : dif;
+                if (d > 0.0f) thr++;
+                if (d < 0.0f) thr--;
+                if (thr > thresh) {
+                    index = (index + 1) % kPhases; thr = 0;
+                    if (index == 0) { clk = 1; if (m_idx >= 0 && lane == 0) sh.out[m_idx] = 0.0f; m_idx++; }
+                }
+                if (thr < -thresh) {
+                    thr = 0; index = (index + kPhases - 1) % kPhases;
+                    if (index == kPhases - 1) { clk = 1; m_idx--; }
+                }
+                p++;
+                continue;
+            }
+            // speculative pass: lane k is the filter tick at input p+2k and the vote tick after it
+            const int nf = min(64, (kDiscOut - p + 1) >> 1);
+            const int ik = p + 2 * lane;
+            const bool have = lane < nf;
+            float s = 0.0f, d = 0.0f;
+            {
+                const float *mf = c_tab.mf[index];
+                const float *md = c_tab.md[index];
+                const int base = have ? ik : p;
+                float xv = sh.x[base];
+                s = xv * mf[0];
+                d = xv * md[0];
+#pragma unroll
+                for (int j = 1; j < kTaps; ++j) {
+                    xv = sh.x[base + j];
+                    s += xv * mf[j];
+                    d += xv * md[j];
+                }
+            }
+            const bool vote_ok = have && (ik + 1 < kDiscOut);
+            const float dd = (s < 0.0f) ? -d : d;
+            const unsigned long long up = __ballot(vote_ok && dd > 0.0f);
+            const unsigned long long dn = __ballot(vote_ok && dd < 0.0f);
+            const unsigned long long incl = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+            const int tk = thr + __popcll(up & incl) - __popcll(dn & incl);
+            const unsigned long long cross = __ballot(vote_ok && (tk > thresh || tk < -thresh));
+            int naccept = nf;
+            int kstar = -1;
+            if (cross) { kstar = __ffsll((long long)cross) - 1; naccept = kstar + 1; }
+            if (lane < naccept && (m_idx + lane) >= 0) sh.out[m_idx + lane] = s;
+            m_idx += naccept;
+            sum = bcast_lane(s, naccept - 1);
+            dif = bcast_lane(d, naccept - 1);
+            if (cross) {
+                const int tstar = bcast_lane_i(tk, kstar);
+                thr = 0;
+                clk = 0;
+                if (tstar > thresh) {
+                    index = (index + 1) % kPhases;
+                    if (index == 0) { clk = 1; if (m_idx >= 0 && lane == 0) sh.out[m_idx] = 0.0f; m_idx++; }
+                } else {
+                    index = (index + kPhases - 1) % kPhases;
+                    if (index == kPhases - 1) { clk = 1; m_idx--; }
+                }
+                p = p + 2 * kstar + 2;
+            } else {
+                thr = thr + __popcll(up) - __popcll(dn);
+                const int ilast = p + 2 * (nf - 1);
+                if (ilast + 1 < kDiscOut) { clk = 0; p = ilast + 2; }
+                else { clk = 1; p = kDiscOut; }
+            }
+        }
+        const int n = m_idx > 0 ? m_idx : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        // delay line for the next block: last 30 inputs
+        {
+            float keep = 0.0f;
+            if (lane < kTaps - 1) keep = sh.x[kDiscOut + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < kTaps - 1) sh.x[lane] = keep;
+        }
+        // symbols out (optional) + framer input h[8+j]
+        for (int q = lane; q < n; q += 64) {
+            const float v = sh.out[q];
+            sh.h[8 + q] = v;
+            if (syms) syms[sym_base + sym_total + q] = v;
+        }
+        if (nsyms && lane == 0) nsyms[(size_t)chan * nblk + b] = n;
+        sym_total += n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        // ---- framer (m17_rx_frame.cpp:126-177)
+        int pos = 0;
+        while (pos < n) {
+            if (flock) {
+                const int t = min(kFrameSyms - fclk, n - pos);
+                for (int q = lane; q < t; q += 64) sh.f[fclk + q] = sh.h[8 + pos + q];
+                fclk += t; pos += t;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (fclk == kFrameSyms) {
+                    fclk = 0;
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = sh.f[i];
+                    const SyncResult r = sync_check(v);
+                    uint32_t flags = 0;
+                    bool parse = false, unlock = false;
+                    if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
+                    else if (sync_accept(r, true)) { flags |= M17_F_SYNC_OK; parse = true; ferr = 0; }
+                    else {
+                        ferr++;
+                        if (ferr > 5) { flags |= M17_F_LOST; unlock = true; }
+                        else parse = true;
+                    }
+                    if (parse && mode == 1) flags |= M17_F_PARSED;
+                    const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
+                    emit_record(crecs, rec_cap, nrec, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
+                    if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
+                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kFrameSyms;
+                        for (int q = lane; q < kFrameSyms; q += 64) fd[q] = sh.f[q];
+                        if (lane == 0) work[atomicAdd(nwork, 1)] = chan * rec_cap + nrec;
+                    }
+                    nrec++;
+                    if (unlock) {
+                        flock = 0;
+                        // reset_sync(): the next hunt windows must see zeros behind them
+                        if (lane < 8) sh.h[pos + lane] = 0.0f;
+                        if (lane < 8) cs.sync[lane] = 0.0f;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                }
+            } else {
+                // hunt: candidate j = pos+lane, window = m_sync after shifting symbol j in
+                const int j = pos + lane;
+                const bool cand = j < n;
+                const int jj = cand ? j : pos;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = sh.h[jj + 1 + i];
+                const SyncResult r = sync_check(v);
+                const unsigned long long hit = __ballot(cand && sync_accept(r, false));
+                if (hit) {
+                    const int l = __ffsll((long long)hit) - 1;
+                    const int js = pos + l;
+                    // copy_sync(); m_fclk = 8; lock; m17_aos()
+                    if (lane < 8) { const float w = sh.h[js + 1 + lane]; sh.f[lane] = w; cs.sync[lane] = w; }
+                    fclk = 8; ferr = 0; flock = 1;
+                    const int ty = bcast_lane_i(r.type, l), vo = bcast_lane_i(r.votes, l);
+                    const float va = bcast_lane(r.variance, l);
+                    emit_record(crecs, rec_cap, nrec, (uint32_t)ty | ((uint32_t)vo << 8), M17_F_AOS, va,
+                                block_count, (uint32_t)js);
+                    nrec++;
+                    pos = js + 1;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                } else {
+                    pos = min(n, pos + 64);
+                }
+            }
+        }
+        // m_sync for the next block while hunting: last 8 entries of h
+        if (!flock) {
+            float keep = 0.0f;
+            if (lane < 8) keep = sh.h[n + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 8) { sh.h[lane] = keep; cs.sync[lane] = keep; }
+        }
+        block_count++;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+
+    // ---- store state
+    if (lane == 0) {
+        cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum; cs.dif = dif;
+        cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count;
+        cs.buff[0] = 0.0f;
+    }
+    if (lane < kTaps - 1) cs.buff[lane + 1] = sh.x[lane];
+    for (int q = lane; q < kFrameSyms; q += 64) cs.fsym[q] = sh.f[q];
+    if (counts && lane == 0) counts[chan] = nrec;
+}
+
+// ---------------------------------------------------------------------------
+// frame decode: 16 lanes per frame
+// ---------------------------------------------------------------------------
+constexpr int DEC_FRAMES_PER_WG = 16;          // 256 threads
+
+struct DecShared {
+    float sym[kFrameSyms];
+    float soft[kSoftBits];
+    float dep[488];
+    uint16_t dec[244];
+    uint8_t bits[248];
+    uint8_t bytes[32];
+};
+
+__device__ __forceinline__ float shfl16(float v, int src_in_group)
+{
+    const int lane = lane_id();
+    const int src = (lane & 48) | (src_in_group & 15);
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ int shfl16i(int v, int src_in_group)
+{
+    const int lane = lane_id();
+    const int src = (lane & 48) | (src_in_group & 15);
+    return __builtin_amdgcn_ds_bpermute(src << 2, v);
+}
+
+__device__ __forceinline__ void group_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// m17_dsp_demap_frame (m17_dsp.cpp:82-95): sym[192] -> soft[368]
+__device__ __forceinline__ void demap16(const float *sym, float *soft, int ln)
+{
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += fabsf(sym[i]);
+    const float cor = 8.0f / sum;              // (float)(8.0/(double)sum), see limit()
+    for (int i = 8 + ln; i < kFrameSyms; i += 16) {
+        const float m = sym[i] * cor;
+        soft[2 * (i - 8)]     = -m;
+        soft[2 * (i - 8) + 1] = (float)((double)fabsf(m) - 0.6666);
+    }
+}
+
+// m17_viterbi_decode (m17_conv.cpp:148-168) with one state per lane.
+// dep[0..len) soft bits in LDS; writes bits[0..len/2) (one bit per byte) to LDS.
+__device__ __forceinline__ void viterbi16(const float *dep, int len, uint16_t *dec, uint8_t *bits, int ln)
+{
+    const int steps = len >> 1;
+    // branch metric selectors (m17_conv.cpp:93-108): metric[idx] = (idx&2 ? m1 : -m1) + (idx&1 ? m2 : -m2)
+    const int ie = c_tab.bm_even[ln], io = c_tab.bm_odd[ln];
+    float acm = (ln == 0) ? 1.0f : 0.0f;                 // :150-153
+    const int grp_shift = (lane_id() & 48);
+    for (int t = 0; t < steps; ++t) {
+        const float m1 = dep[2 * t], m2 = dep[2 * t + 1];
+        const float n1 = -m1, n2 = -m2;
+        const float me = ((ie & 2) ? m1 : n1) + ((ie & 1) ? m2 : n2);
+        const float mo = ((io & 2) ? m1 : n1) + ((io & 1) ? m2 : n2);
+        const float pe = shfl16(acm, 2 * ln), po = shfl16(acm, 2 * ln + 1);
+        const float ta = pe + me, tb = po + mo;
+        const bool take_even = ta > tb;                  // strict '>' : ties pick the odd predecessor
+        acm = take_even ? ta : tb;
+        const unsigned long long odd = __ballot(!take_even);
+        if (ln == 0) dec[t] = (uint16_t)(odd >> grp_shift);
+    }
+    group_sync();
+    if (ln == 0) {
+        int state = 0;                                   // traceback from state 0 (:160-166)
+        for (int t = steps - 1; t >= 0; --t) {
+            const int d = dec[t];
+            state = ((state << 1) & 15) | ((d >> state) & 1);
+            bits[t] = (uint8_t)(state >> 3);
+        }
+    }
+    group_sync();
+}
+
+// pack_1_to_8(&bits[1], out, nbits) (m17_bit_utils.cpp:26-32)
+__device__ __forceinline__ void pack_bits16(const uint8_t *bits, uint8_t *out, int nbytes, int ln)
+{
+    for (int by = ln; by < nbytes; by += 16) {
+        int v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v = (v << 1) | bits[1 + by * 8 + k];
+        out[by] = (uint8_t)v;
+    }
+}
+
+// m_17_golay_decode (m17_golay.cpp:103-116)
+__device__ __forceinline__ int golay_decode(uint32_t word, const uint16_t *enc, const uint16_t *err, int &errs)
+{
+    const uint32_t data = (word >> 12) & 0xFFF, par = word & 0xFFF;
+    const uint32_t syn = par ^ enc[data];
+    const uint32_t e = err[syn];
+    errs = (int)((e & 0xF000) >> 12);
+    return (int)(data ^ (e & 0xFFF));
+}
+
+__device__ void decode_frame16(DecShared &sh, int type, int ln,
+                               const uint16_t *genc, const uint16_t *gerr,
+                               uint32_t &fn_out, uint32_t &gerrs_out)
+{
+    demap16(sh.sym, sh.soft, ln);
+    group_sync();
+    const int len = c_tab.glen[type];
+    // fused m17_de_correlate_1 . m17_de_interleave . m17_de_punc_pN (m17_rx_parse.cpp:90-94 etc.)
+    for (int k = ln; k < len; k += 16) {
+        const int g = c_tab.gather[type][k];
+        float v = 0.0f;                                  // erasure (m17_puncture.cpp:54)
+        if (g >= 0) { v = sh.soft[g & 0x3FF]; if (g & 0x4000) v = -v; }
+        sh.dep[k] = v;
+    }
+    fn_out = 0; gerrs_out = 0;
+    if (type == 2) {
+        // LICH: four Golay words from de-interleaved positions 0..95 (m17_rx_parse.cpp:118-135)
+        int w = 0, e = 0;
+        if (ln < 4) {
+            uint32_t word = 0;
+            for (int k = 0; k < 24; ++k) {
+                const int g = c_tab.lich[ln * 24 + k];
+                float v = sh.soft[g & 0x3FF]; if (g & 0x4000) v = -v;
+                word = (word << 1) | (v >= 0.0f ? 1u : 0u);        // hard_decode_24_bits
+            }
+            w = golay_decode(word, genc, gerr, e);
+        }
+        const int w0 = shfl16i(w, 0), w1 = shfl16i(w, 1), w2 = shfl16i(w, 2), w3 = shfl16i(w, 3);
+        const int es = shfl16i(e, 0) + shfl16i(e, 1) + shfl16i(e, 2) + shfl16i(e, 3);
+        gerrs_out = (uint32_t)es;
+        if (ln == 0) {                                              // pack_12_to_8_x4x6
+            const uint32_t a = ((uint32_t)w0 << 12) | (uint32_t)w1, b = ((uint32_t)w2 << 12) | (uint32_t)w3;
+            sh.bytes[0] = (uint8_t)(a >> 16); sh.bytes[1] = (uint8_t)(a >> 8); sh.bytes[2] = (uint8_t)a;
+            sh.bytes[3] = (uint8_t)(b >> 16); sh.bytes[4] = (uint8_t)(b >> 8); sh.bytes[5] = (uint8_t)b;
+        }
+    }
+    group_sync();
+    viterbi16(sh.dep, len, sh.dec, sh.bits, ln);
+    if (type == 1) pack_bits16(sh.bits, sh.bytes, 30, ln);
+    else if (type == 2) pack_bits16(sh.bits, sh.bytes + 6, 18, ln);
+    else pack_bits16(sh.bits, sh.bytes, 26, ln);
+    group_sync();
+    if (type == 2) fn_out = ((uint32_t)sh.bytes[6] << 8) | sh.bytes[7];            // pack_8_to_16
+    if (type == 3) fn_out = ((uint32_t)(sh.bytes[25] >> 7) << 8) | ((sh.bytes[25] >> 2) & 0x1F);
+}
+
+// work-list driven decode of the frames k_sync_frame queued; or, with work ==
+// nullptr, a plain batch (frame i, type from types[i]) for the stage entry point
+__global__ __launch_bounds__(256)
+void k_decode(const float *__restrict__ fsym, const int32_t *__restrict__ work,
+              const int32_t *__restrict__ nwork, int nmax, const uint8_t *__restrict__ types,
+              m17gpu_rec_dev *__restrict__ recs,
+              const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr)
+{
+    __shared__ DecShared sh_all[DEC_FRAMES_PER_WG];
+    const int g = (int)(threadIdx.x >> 4), ln = (int)(threadIdx.x & 15);
+    const int total = work ? min(*nwork, nmax) : nmax;
+    DecShared &sh = sh_all[g];
+    // grid-stride over the work list; the 4 groups of a wave share ballot /
+    // bpermute instructions, so a group past the end repeats the last item
+    // instead of exiting and simply does not write back
+    for (int base = (int)blockIdx.x * DEC_FRAMES_PER_WG; base < total; base += (int)gridDim.x * DEC_FRAMES_PER_WG) {
+        const int item = base + g;
+        const bool active = item < total;
+        const int it = active ? item : total - 1;
+        const int slot = work ? work[it] : it;
+        m17gpu_rec_dev &rec = recs[slot];
+        int type = work ? (int)rec.type : (int)types[it];
+        const bool decodable = type >= 1 && type <= 3;
+        if (!decodable) type = 1;
+        const float *src = fsym + (size_t)slot * kFrameSyms;
+        for (int q = ln; q < kFrameSyms; q += 16) sh.sym[q] = src[q];
+        if (ln < 8) reinterpret_cast<uint32_t *>(sh.bytes)[ln] = 0;
+        group_sync();
+        uint32_t fn, ge;
+        decode_frame16(sh, type, ln, genc, gerr, fn, ge);
+        if (active && decodable) {
+            uint32_t *r = reinterpret_cast<uint32_t *>(&rec);
+            if (ln < 8) r[5 + ln] = reinterpret_cast<const uint32_t *>(sh.bytes)[ln];
+            if (ln == 8) {
+                if (!work) r[0] = (uint32_t)type;
+                r[0] = (r[0] & 0xFF00FFFFu) | ((ge & 0xFF) << 16);
+                r[1] = (r[1] & 0x0000FFFFu) | (fn << 16);
+            }
+        }
+        group_sync();
+    }
+}
+
+// stand-alone stage kernels -------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_viterbi(const float *__restrict__ soft, uint8_t *__restrict__ bits, int len, int n)
+{
+    __shared__ DecShared sh_all[DEC_FRAMES_PER_WG];
+    const int g = (int)(threadIdx.x >> 4), ln = (int)(threadIdx.x & 15);
+    const int item = (int)blockIdx.x * DEC_FRAMES_PER_WG + g;
+    const bool active = item < n;
+    const int it = active ? item : n - 1;
+    DecShared &sh = sh_all[g];
+    for (int q = ln; q < len; q += 16) sh.dep[q] = soft[(size_t)it * len + q];
+    group_sync();
+    viterbi16(sh.dep, len, sh.dec, sh.bits, ln);
+    if (active)
+        for (int q = ln; q < (len >> 1); q += 16) bits[(size_t)it * (len >> 1) + q] = sh.bits[q];
+}
+
+__global__ __launch_bounds__(256)
+void k_demap(const float *__restrict__ sym, float *__restrict__ soft, int n)
+{
+    __shared__ DecShared sh_all[DEC_FRAMES_PER_WG];
+    const int g = (int)(threadIdx.x >> 4), ln = (int)(threadIdx.x & 15);
+    const int item = (int)blockIdx.x * DEC_FRAMES_PER_WG + g;
+    const bool active = item < n;
+    const int it = active ? item : n - 1;
+    DecShared &sh = sh_all[g];
+    for (int q = ln; q < kFrameSyms; q += 16) sh.sym[q] = sym[(size_t)it * kFrameSyms + q];
+    group_sync();
+    demap16(sh.sym, sh.soft, ln);
+    group_sync();
+    if (active)
+        for (int q = ln; q < kSoftBits; q += 16) soft[(size_t)it * kSoftBits + q] = sh.soft[q];
+}
+
+__global__ void k_golay(const uint32_t *__restrict__ words, uint16_t *__restrict__ out, int n,
+                        const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    int e;
+    const int d = golay_decode(words[i], genc, gerr, e);
+    out[i] = (uint16_t)(d | (e << 12));
+}
+
+// ---------------------------------------------------------------------------
+// k_lsf: per-channel, in-order bookkeeping of what m17_rx_parse / m17_aos /
+// m17_los do to file-static state (m17_rx_parse.cpp:34-101,144-158; m17_dbase.cpp:60-82)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t crc16_dev(const uint8_t *p, int n)
+{
+    uint32_t crc = 0xFFFF;
+    for (int i = 0; i < n; ++i)
+        crc = ((crc << 8) ^ c_tab.crc[((crc >> 8) ^ p[i]) & 0xFF]) & 0xFFFF;
+    return crc;
+}
+
+__global__ __launch_bounds__(64)
+void k_lsf(ChanState *__restrict__ st, int C, m17gpu_rec_dev *__restrict__ recs, int rec_cap,
+           const int32_t *__restrict__ counts)
+{
+    const int chan = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (chan >= C) return;
+    ChanState &cs = st[chan];
+    const int n = min(counts[chan], rec_cap);
+    for (int i = 0; i < n; ++i) {
+        m17gpu_rec_dev &r = recs[(size_t)chan * rec_cap + i];
+        uint32_t flags = r.flags;
+        if (flags & M17_F_AOS) { cs.g_errors = 0; cs.n_frames = 0; cs.in_frame = 1; cs.frame_id_epoch++; continue; }
+        if (flags & (M17_F_EOT | M17_F_LOST)) { cs.in_frame = 0; cs.frame_id_epoch++; continue; }
+        if (!(flags & M17_F_PARSED)) continue;
+        const int type = r.type;
+        if (type == 0 || type == 5) { cs.frame_id_epoch++; }
+        else if (type == 1) {
+            if (crc16_dev(cs.packet, 30) == 0) flags |= M17_F_LSF_GATE;        // m17_rx_parse.cpp:98
+        } else if (type == 2) {
+            cs.g_errors += r.golay_errs; cs.n_frames++;
+            const int seq = r.data[5] >> 5;                                    // update_lich :71-85
+            if (seq < 6) {
+                for (int k = 0; k < 5; ++k) cs.lsf[0][seq * 5 + k] = r.data[k];
+                if (crc16_dev(cs.lsf[0], 30) == 0) {
+                    for (int k = 0; k < 30; ++k) cs.lsf[1][k] = cs.lsf[0][k];
+                    flags |= M17_F_LICH_OK;
+                }
+            }
+            if (crc16_dev(cs.lsf[1], 30) == 0) flags |= M17_F_DELIVERED;       // :148
+        } else if (type == 3) {
+            const int eof = r.data[25] >> 7, fn = (r.data[25] >> 2) & 0x1F;    // parse_packet :34-51
+            if (eof) {
+                int cnt = fn;
+                if (cs.packet_idx + cnt > 800) cnt = 800 - cs.packet_idx;
+                for (int k = 0; k < cnt; ++k) cs.packet[cs.packet_idx + k] = r.data[k];
+                cs.packet_idx += cnt;
+                if (crc16_dev(cs.packet, cs.packet_idx) == 0) flags |= M17_F_PKT_VALID;
+                cs.packet_idx = 0;
+            } else {
+                for (int k = 0; k < 25; ++k) cs.packet[fn * 25 + k] = r.data[k];
+                cs.packet_idx = fn * 25;
+            }
+        }
+        r.flags = (uint16_t)flags;
+    }
+}
+
+__global__ void k_reset(ChanState *st, int C)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int words = (int)(sizeof(ChanState) / 4);
+    if (i >= C * words) return;
+    uint32_t *p = reinterpret_cast<uint32_t *>(st);
+    const int w = i % words;
+    uint32_t v = 0;
+    if (w == (int)(offsetof(ChanState, clk) / 4)) v = 1;          // m17_rx_sync.cpp:123
+    if (w == (int)(offsetof(ChanState, index) / 4)) v = 10;       // :126
+    p[i] = v;
+}
+
+} // namespace m17dev

@@ -1,0 +1,305 @@
+// m17gpu_capi.hip -- the C-ABI of include/m17gpu.h on top of the gfx950 kernels.
+// No CPU fallback: every compute entry point needs a HIP device.
+#include "m17_kernels.hip"
+#include "m17_host.h"
+#include "../../include/m17gpu.h"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <new>
+
+using namespace m17dev;
+
+static_assert(sizeof(m17gpu_rec) == sizeof(m17gpu_rec_dev), "record layouts must agree");
+static_assert(offsetof(m17gpu_rec, data) == offsetof(m17gpu_rec_dev, data), "record layouts must agree");
+static_assert(offsetof(m17gpu_rec, variance) == 8 && offsetof(m17gpu_rec, block) == 12 &&
+              offsetof(m17gpu_rec, sym_pos) == 16 && offsetof(m17gpu_rec, data) == 20, "record word layout");
+
+struct m17gpu_ctx {
+    int device = 0, C = 0, max_blocks = 0, rec_cap_max = 0;
+    ChanState *d_state = nullptr;
+    float *d_disc = nullptr, *d_offs = nullptr, *d_fsym = nullptr;
+    int32_t *d_work = nullptr, *d_nwork = nullptr, *d_counts = nullptr;
+    uint16_t *d_genc = nullptr, *d_gerr = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(M17GPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int upload_tables(m17gpu_ctx *ctx)
+{
+    const m17::Tables &T = m17::tables();
+    static DevTables h;                      // too large for the stack of some callers
+    std::memset(&h, 0, sizeof h);
+    for (int p = 0; p < kPhases; ++p)
+        for (int j = 0; j < kTaps; ++j) { h.mf[p][j] = T.mf[p][j]; h.md[p][j] = T.md[p][j]; }
+    for (int t = 0; t < 4; ++t) {
+        h.glen[t] = T.glen[t];
+        for (int k = 0; k < 488; ++k) {
+            int16_t g = T.gather[t][k];
+            if (t == 0 || k >= T.glen[t]) g = -1;
+            else if (g >= 0 && T.gsign[t][k] < 0) g = (int16_t)(g | 0x4000);
+            h.gather[t][k] = g;
+        }
+    }
+    for (int j = 0; j < 96; ++j)
+        h.lich[j] = (int16_t)(T.lich_src[j] | (T.lich_sign[j] < 0 ? 0x4000 : 0));
+    std::memcpy(h.bm_even, T.bm_even, 16);
+    std::memcpy(h.bm_odd, T.bm_odd, 16);
+    std::memcpy(h.crc, T.crc, sizeof h.crc);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &h, sizeof h));
+    HIPCHK(hipMalloc(&ctx->d_genc, 4096 * sizeof(uint16_t)));
+    HIPCHK(hipMalloc(&ctx->d_gerr, 4096 * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(ctx->d_genc, T.golay_enc, 4096 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_gerr, T.golay_err, 4096 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return M17GPU_OK;
+}
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc, float *offs,
+                    int update_state, hipStream_t st)
+{
+    const int total = ctx->C * nblk;
+    hipLaunchKernelGGL(k_frontend, dim3(cdiv(total, 64 * FE_WAVES)), dim3(64 * FE_WAVES), 0, st,
+                       reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, disc, offs, nblk, total, update_state);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int nblk, int mode,
+                      m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, float *d_syms, int32_t *d_nsyms,
+                      hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sync_frame, dim3(cdiv(ctx->C, SF_WAVES)), dim3(64 * SF_WAVES), 0, st,
+                       disc, offs, ctx->d_state, ctx->C, nblk, mode,
+                       reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
+                       d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
+                       ctx->d_fsym, ctx->d_work, ctx->d_nwork);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *m17gpu_last_error(void) { return g_err.c_str(); }
+
+int m17gpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int m17gpu_channels(const m17gpu_ctx *ctx) { return ctx ? ctx->C : 0; }
+
+int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
+{
+    if (!out || n_channels <= 0 || max_blocks <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_create: bad argument");
+    if (m17gpu_device_count() <= 0)
+        return fail(M17GPU_ERR_NO_DEVICE, "m17gpu_create: no HIP device visible (there is no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    m17gpu_ctx *ctx = new (std::nothrow) m17gpu_ctx;
+    if (!ctx) return fail(M17GPU_ERR_NOMEM, "m17gpu_create: out of host memory");
+    ctx->device = device; ctx->C = n_channels; ctx->max_blocks = max_blocks;
+    ctx->rec_cap_max = 2 * max_blocks + 2;
+    const size_t cb = (size_t)n_channels * max_blocks;
+    int rc = upload_tables(ctx);
+    if (rc != M17GPU_OK) { m17gpu_destroy(ctx); return rc; }
+#define ALLOC(ptr, bytes)                                                               \
+    do {                                                                               \
+        hipError_t e_ = hipMalloc(reinterpret_cast<void **>(&(ptr)), (bytes));          \
+        if (e_ != hipSuccess) { m17gpu_destroy(ctx);                                     \
+            return fail(M17GPU_ERR_NOMEM, std::string("hipMalloc " #ptr ": ") + hipGetErrorString(e_)); } \
+    } while (0)
+    ALLOC(ctx->d_state, sizeof(ChanState) * (size_t)n_channels);
+    ALLOC(ctx->d_disc, sizeof(float) * cb * kDiscOut);
+    ALLOC(ctx->d_offs, sizeof(float) * cb);
+    ALLOC(ctx->d_fsym, sizeof(float) * (size_t)n_channels * ctx->rec_cap_max * kFrameSyms);
+    ALLOC(ctx->d_work, sizeof(int32_t) * (size_t)n_channels * ctx->rec_cap_max);
+    ALLOC(ctx->d_nwork, sizeof(int32_t) * 4);
+    ALLOC(ctx->d_counts, sizeof(int32_t) * (size_t)n_channels);
+#undef ALLOC
+    rc = m17gpu_reset(ctx, nullptr);
+    if (rc != M17GPU_OK) { m17gpu_destroy(ctx); return rc; }
+    HIPCHK(hipDeviceSynchronize());
+    *out = ctx;
+    return M17GPU_OK;
+}
+
+void m17gpu_destroy(m17gpu_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    void *bufs[] = {ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->d_fsym, ctx->d_work,
+                    ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr};
+    for (void *p : bufs) (void)hipFree(p);
+    delete ctx;
+}
+
+int m17gpu_reset(m17gpu_ctx *ctx, void *stream)
+{
+    if (!ctx) return fail(M17GPU_ERR_ARG, "m17gpu_reset: null context");
+    const long long words = (long long)ctx->C * (long long)(sizeof(ChanState) / 4);
+    hipLaunchKernelGGL(k_reset, dim3(cdiv(words, 256)), dim3(256), 0, S(stream), ctx->d_state, ctx->C);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
+                     m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts,
+                     float *d_syms, int32_t *d_nsyms, void *stream)
+{
+    if (!ctx || !d_iq || nblk <= 0 || nblk > ctx->max_blocks || rec_cap < 0)
+        return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: bad argument (nblk must be 1..max_blocks)");
+    if (mode == 1 && (!d_recs || rec_cap <= 0 || rec_cap > ctx->rec_cap_max))
+        return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: mode 1 needs d_recs and 0 < rec_cap <= 2*max_blocks+2");
+    hipStream_t st = S(stream);
+    int rc;
+    if (mode == 1) HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t), st));
+    if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, st)) != M17GPU_OK) return rc;
+    if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
+                                d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
+    if (mode == 1) {
+        const long long slots = (long long)ctx->C * rec_cap;
+        int grid = cdiv(slots, DEC_FRAMES_PER_WG);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(k_decode, dim3(grid), dim3(256), 0, st, ctx->d_fsym, ctx->d_work, ctx->d_nwork,
+                           (int)slots, (const uint8_t *)nullptr, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
+                           ctx->d_genc, ctx->d_gerr);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_lsf, dim3(cdiv(ctx->C, 64)), dim3(64), 0, st, ctx->d_state, ctx->C,
+                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap,
+                           d_counts ? d_counts : ctx->d_counts);
+        HIPCHK(hipGetLastError());
+    }
+    return M17GPU_OK;
+}
+
+int m17gpu_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *d_disc, float *d_offset, void *stream)
+{
+    if (!ctx || !d_iq || !d_disc || nblk <= 0 || nblk > ctx->max_blocks)
+        return fail(M17GPU_ERR_ARG, "m17gpu_frontend: bad argument");
+    hipStream_t st = S(stream);
+    float *offs = d_offset ? d_offset : ctx->d_offs;
+    int rc = launch_frontend(ctx, d_iq, nblk, d_disc, offs, 1, st);
+    if (rc != M17GPU_OK) return rc;
+    const long long n = (long long)ctx->C * nblk * kDiscOut;
+    hipLaunchKernelGGL(k_dc_remove, dim3(cdiv(n, 256)), dim3(256), 0, st, d_disc, offs, ctx->C * nblk);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+int m17gpu_sync_frame(m17gpu_ctx *ctx, const float *d_disc, int nblk, m17gpu_rec *d_recs, int rec_cap,
+                      int32_t *d_counts, float *d_syms, int32_t *d_nsyms, void *stream)
+{
+    if (!ctx || !d_disc || nblk <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_sync_frame: bad argument");
+    return launch_sync_frame(ctx, d_disc, nullptr, nblk, 0, d_recs, rec_cap, d_counts, d_syms, d_nsyms, S(stream));
+}
+
+int m17gpu_viterbi_decode(m17gpu_ctx *ctx, const float *d_soft, uint8_t *d_bits, int len, int n, void *stream)
+{
+    if (!ctx || !d_soft || !d_bits || len <= 0 || len > 488 || (len & 1) || n <= 0)
+        return fail(M17GPU_ERR_ARG, "m17gpu_viterbi_decode: len must be even and <= 488");
+    hipLaunchKernelGGL(k_viterbi, dim3(cdiv(n, DEC_FRAMES_PER_WG)), dim3(256), 0, S(stream), d_soft, d_bits, len, n);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+int m17gpu_demap_frame(m17gpu_ctx *ctx, const float *d_sym, float *d_soft, int n, void *stream)
+{
+    if (!ctx || !d_sym || !d_soft || n <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_demap_frame: bad argument");
+    hipLaunchKernelGGL(k_demap, dim3(cdiv(n, DEC_FRAMES_PER_WG)), dim3(256), 0, S(stream), d_sym, d_soft, n);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+int m17gpu_decode_frames(m17gpu_ctx *ctx, const float *d_sym, const uint8_t *d_type, m17gpu_rec *d_recs, int n, void *stream)
+{
+    if (!ctx || !d_sym || !d_type || !d_recs || n <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_decode_frames: bad argument");
+    hipStream_t st = S(stream);
+    HIPCHK(hipMemsetAsync(d_recs, 0, sizeof(m17gpu_rec) * (size_t)n, st));
+    int grid = cdiv(n, DEC_FRAMES_PER_WG);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_decode, dim3(grid), dim3(256), 0, st, d_sym, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr, n, d_type, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
+                       ctx->d_genc, ctx->d_gerr);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_out, int n, void *stream)
+{
+    if (!ctx || !d_words || !d_out || n <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_golay_decode: bad argument");
+    hipLaunchKernelGGL(k_golay, dim3(cdiv(n, 256)), dim3(256), 0, S(stream), d_words, d_out, n, ctx->d_genc, ctx->d_gerr);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+static int fetch_state(m17gpu_ctx *ctx, std::vector<ChanState> &h)
+{
+    h.resize((size_t)ctx->C);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(h.data(), ctx->d_state, sizeof(ChanState) * (size_t)ctx->C, hipMemcpyDeviceToHost));
+    return M17GPU_OK;
+}
+
+int m17gpu_get_lsf(m17gpu_ctx *ctx, uint8_t *h_lsf)
+{
+    if (!ctx || !h_lsf) return fail(M17GPU_ERR_ARG, "m17gpu_get_lsf: bad argument");
+    std::vector<ChanState> h; int rc = fetch_state(ctx, h); if (rc) return rc;
+    for (int c = 0; c < ctx->C; ++c)
+        for (int k = 0; k < 2; ++k) std::memcpy(h_lsf + ((size_t)c * 2 + k) * 30, h[c].lsf[k], 30);
+    return M17GPU_OK;
+}
+
+int m17gpu_get_counters(m17gpu_ctx *ctx, uint32_t *h_cnt)
+{
+    if (!ctx || !h_cnt) return fail(M17GPU_ERR_ARG, "m17gpu_get_counters: bad argument");
+    std::vector<ChanState> h; int rc = fetch_state(ctx, h); if (rc) return rc;
+    for (int c = 0; c < ctx->C; ++c) {
+        h_cnt[4 * c + 0] = h[c].g_errors; h_cnt[4 * c + 1] = h[c].n_frames;
+        h_cnt[4 * c + 2] = h[c].in_frame; h_cnt[4 * c + 3] = h[c].frame_id_epoch;
+    }
+    return M17GPU_OK;
+}
+
+int m17gpu_get_lock(m17gpu_ctx *ctx, uint8_t *h_lock)
+{
+    if (!ctx || !h_lock) return fail(M17GPU_ERR_ARG, "m17gpu_get_lock: bad argument");
+    std::vector<ChanState> h; int rc = fetch_state(ctx, h); if (rc) return rc;
+    for (int c = 0; c < ctx->C; ++c) h_lock[c] = (uint8_t)(h[c].flock != 0);
+    return M17GPU_OK;
+}
+
+int m17gpu_get_taps(float *h_mf, float *h_md)
+{
+    const m17::Tables &T = m17::tables();
+    if (h_mf) std::memcpy(h_mf, T.mf, sizeof T.mf);
+    if (h_md) std::memcpy(h_md, T.md, sizeof T.md);
+    return M17GPU_OK;
+}
+
+int m17gpu_get_golay_tables(uint16_t *h_enc, uint16_t *h_err)
+{
+    const m17::Tables &T = m17::tables();
+    if (h_enc) std::memcpy(h_enc, T.golay_enc, sizeof T.golay_enc);
+    if (h_err) std::memcpy(h_err, T.golay_err, sizeof T.golay_err);
+    return M17GPU_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,123 @@
+"""ctypes wrapper of the CPU oracle (oracle/libm17oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py; never by the product package."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATH = os.path.join(ROOT, "oracle", "libm17oracle.so")
+
+
+class Rec(C.Structure):
+    _fields_ = [("type", C.c_uint8), ("votes", C.c_uint8), ("golay_errs", C.c_uint8),
+                ("frame_errors", C.c_uint8), ("flags", C.c_uint16), ("fn", C.c_uint16),
+                ("variance", C.c_float), ("block", C.c_uint32), ("sym_pos", C.c_uint16),
+                ("rsv0", C.c_uint16), ("data", C.c_uint8 * 32), ("rsv", C.c_uint8 * 12)]
+
+
+REC_DTYPE = np.dtype([("type", "u1"), ("votes", "u1"), ("golay_errs", "u1"), ("frame_errors", "u1"),
+                      ("flags", "<u2"), ("fn", "<u2"), ("variance", "<f4"), ("block", "<u4"),
+                      ("sym_pos", "<u2"), ("rsv0", "<u2"), ("data", "u1", (32,)), ("rsv", "u1", (12,))])
+assert REC_DTYPE.itemsize == 64
+
+_L = None
+
+
+def L():
+    global _L
+    if _L is None:
+        lib = C.CDLL(PATH)
+        lib.m17o_init()
+        lib.m17o_crc.restype = C.c_uint16
+        lib.m17o_golay_encode.restype = C.c_uint32
+        lib.m17o_encode_call.restype = C.c_uint64
+        for n in ("m17o_tab_mf", "m17o_tab_md"):
+            getattr(lib, n).restype = C.POINTER(C.c_float)
+        for n in ("m17o_tab_golay_enc", "m17o_tab_golay_err", "m17o_tab_crc"):
+            getattr(lib, n).restype = C.POINTER(C.c_uint16)
+        lib.m17o_tab_derand.restype = C.POINTER(C.c_uint8)
+        _L = lib
+    return _L
+
+
+def vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def chan_size():
+    return L().m17o_sizeof_chan()
+
+
+class Channels:
+    """C oracle channel states."""
+
+    def __init__(self, n):
+        self.n = n
+        self.size = chan_size()
+        self.buf = np.zeros((n, self.size), np.uint8)
+        for c in range(n):
+            L().m17o_chan_reset(vp(self.buf[c]))
+
+    def rx_blocks(self, iq, mode=1, cap=None, want_syms=True, nthreads=8):
+        """iq int16 [C, nblk, 1920, 2] -> dict(recs[C,cap], counts[C], syms, nsyms)."""
+        Cn, nblk = iq.shape[0], iq.shape[1]
+        assert Cn == self.n and iq.dtype == np.int16 and iq.flags.c_contiguous
+        cap = cap or (2 * nblk + 2)
+        recs = np.zeros((Cn, cap), REC_DTYPE)
+        counts = np.zeros((Cn,), np.int32)
+        syms = np.zeros((Cn, nblk * 193 + 8), np.float32) if want_syms else None
+        nsyms = np.zeros((Cn, nblk), np.int32) if want_syms else None
+        L().m17o_rx_blocks(vp(self.buf), Cn, nblk, vp(iq), vp(recs), cap, vp(counts),
+                           vp(syms) if want_syms else None, vp(nsyms) if want_syms else None,
+                           int(mode), int(nthreads))
+        return {"recs": recs, "counts": counts, "syms": syms, "nsyms": nsyms}
+
+    def field(self, name):
+        """Selected state fields as arrays (layout of m17o_chan in oracle/m17_oracle.h)."""
+        i32 = self.buf.view(np.int32)
+        f32 = self.buf.view(np.float32)
+        off = {"disc_count": 0, "z": 1, "m_clk": 5, "m_thr": 6, "m_index": 7, "sum": 8, "dif": 9,
+               "m_buff": 10, "m_flock": 41, "m_fclk": 42, "m_frame_errors": 43, "m_sync": 44, "m_f_sym": 52}
+        if name == "z":
+            return f32[:, 1:5]
+        if name in ("sum", "dif"):
+            return f32[:, off[name]]
+        if name == "m_buff":
+            return f32[:, 10:41]
+        if name == "m_sync":
+            return f32[:, 44:52]
+        if name == "m_f_sym":
+            return f32[:, 52:244]
+        if name == "m_lsf":
+            return self.buf[:, 244 * 4: 244 * 4 + 60].reshape(self.n, 2, 30)
+        if name == "counters":       # g_errors, n_frames, in_frame, frame_id_epoch
+            base = 244 * 4 + 60 + 4 + 800 + 4
+            return self.buf[:, base: base + 16].view(np.uint32)
+        return i32[:, off[name]]
+
+
+def frontend(iq_block, state=None):
+    """One channel-block: int16 [1920,2] -> (d[384], d_raw[384], offset)."""
+    st = state if state is not None else Channels(1).buf[0]
+    d = np.zeros(384, np.float32)
+    raw = np.zeros(384, np.float32)
+    off = C.c_float()
+    L().m17o_frontend(vp(st), vp(np.ascontiguousarray(iq_block)), vp(d), vp(raw), C.byref(off))
+    return d, raw, off.value
+
+
+def viterbi(soft):
+    soft = np.ascontiguousarray(soft, np.float32)
+    out = np.zeros(len(soft) // 2, np.uint8)
+    L().m17o_viterbi_decode(vp(soft), vp(out), len(soft))
+    return out
+
+
+def demap(sym):
+    sym = np.ascontiguousarray(sym, np.float32)
+    out = np.zeros(368, np.float32)
+    L().m17o_demap_frame(vp(sym), vp(out))
+    return out
