@@ -121,6 +121,15 @@ int m17gpu_decode_frames(m17gpu_ctx *ctx, const float *d_sym, const uint8_t *d_t
 /* m_17_golay_decode (m17_golay.cpp:103-116) on n 24-bit words: d_out[i] = data | weight<<12 */
 int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_out, int n, void *stream);
 
+/* ---------------- measurement hooks ---------------- */
+/* When on, m17gpu_rx_blocks brackets each of its kernels with HIP events on the
+ * launch stream (up to 512 calls are kept).  m17gpu_get_kernel_ms waits for the
+ * recorded events and returns the average milliseconds per launch of
+ * {k_frontend, k_sync_frame, k_decode, k_lsf} and the number of calls averaged,
+ * then clears the record. */
+int m17gpu_set_profiling(m17gpu_ctx *ctx, int on);
+int m17gpu_get_kernel_ms(m17gpu_ctx *ctx, float h_ms[4], int *h_calls);
+
 /* ---------------- state access (host, synchronous) ---------------- */
 /* the reassembled LSF pair m_lsf[2][30] of each channel (m17_rx_parse.cpp:5) */
 int m17gpu_get_lsf(m17gpu_ctx *ctx, uint8_t *h_lsf /* [C][2][30] */);

@@ -53,6 +53,8 @@ SIGNATURES = {
     "m17gpu_demap_frame": (_i, [_vp, _vp, _vp, _i, _vp]),
     "m17gpu_decode_frames": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "m17gpu_golay_decode": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "m17gpu_set_profiling": (_i, [_vp, _i]),
+    "m17gpu_get_kernel_ms": (_i, [_vp, _vp, _vp]),
     "m17gpu_get_lsf": (_i, [_vp, _vp]),
     "m17gpu_get_counters": (_i, [_vp, _vp]),
     "m17gpu_get_lock": (_i, [_vp, _vp]),

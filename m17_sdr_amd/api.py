@@ -129,6 +129,17 @@ class Receiver:
         _check(lib().m17gpu_golay_decode(self._ctx, _ptr(words), _ptr(out), n, _stream()), "m17gpu_golay_decode")
         return out
 
+    # ---- measurement ---------------------------------------------------------
+    def set_profiling(self, on):
+        _check(lib().m17gpu_set_profiling(self._ctx, int(bool(on))), "m17gpu_set_profiling")
+
+    def kernel_ms(self):
+        """Average ms per launch of (k_frontend, k_sync_frame, k_decode, k_lsf), number of calls."""
+        ms = (C.c_float * 4)()
+        n = C.c_int()
+        _check(lib().m17gpu_get_kernel_ms(self._ctx, ms, C.byref(n)), "m17gpu_get_kernel_ms")
+        return list(ms), n.value
+
     # ---- state -------------------------------------------------------------
     def lsf(self):
         a = np.zeros((self.C, 2, 30), np.uint8)

@@ -22,6 +22,9 @@ struct m17gpu_ctx {
     float *d_disc = nullptr, *d_offs = nullptr, *d_fsym = nullptr;
     int32_t *d_work = nullptr, *d_nwork = nullptr, *d_counts = nullptr;
     uint16_t *d_genc = nullptr, *d_gerr = nullptr;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;         // 5 events per profiled call
+    std::vector<int> ev_mode;                // mode of each profiled call
 };
 
 namespace {
@@ -148,6 +151,7 @@ void m17gpu_destroy(m17gpu_ctx *ctx)
     void *bufs[] = {ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->d_fsym, ctx->d_work,
                     ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr};
     for (void *p : bufs) (void)hipFree(p);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -171,9 +175,24 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
     hipStream_t st = S(stream);
     int rc;
     if (mode == 1) HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t), st));
+    hipEvent_t *ev = nullptr;
+    if (ctx->profiling && ctx->ev_mode.size() < 512) {
+        const size_t base = ctx->ev_pool.size();
+        for (int i = 0; i < 5; ++i) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            ctx->ev_pool.push_back(e);
+        }
+        ctx->ev_mode.push_back(mode);
+        ev = &ctx->ev_pool[base];
+    }
+#define MARK(i) do { if (ev) HIPCHK(hipEventRecord(ev[i], st)); } while (0)
+    MARK(0);
     if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, st)) != M17GPU_OK) return rc;
+    MARK(1);
     if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
                                 d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
+    MARK(2);
     if (mode == 1) {
         const long long slots = (long long)ctx->C * rec_cap;
         int grid = cdiv(slots, DEC_FRAMES_PER_WG);
@@ -182,11 +201,45 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
                            (int)slots, (const uint8_t *)nullptr, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
                            ctx->d_genc, ctx->d_gerr);
         HIPCHK(hipGetLastError());
+        MARK(3);
         hipLaunchKernelGGL(k_lsf, dim3(cdiv(ctx->C, 64)), dim3(64), 0, st, ctx->d_state, ctx->C,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap,
                            d_counts ? d_counts : ctx->d_counts);
         HIPCHK(hipGetLastError());
+        MARK(4);
     }
+#undef MARK
+    return M17GPU_OK;
+}
+
+int m17gpu_set_profiling(m17gpu_ctx *ctx, int on)
+{
+    if (!ctx) return fail(M17GPU_ERR_ARG, "m17gpu_set_profiling: null context");
+    ctx->profiling = on != 0;
+    return M17GPU_OK;
+}
+
+int m17gpu_get_kernel_ms(m17gpu_ctx *ctx, float h_ms[4], int *h_calls)
+{
+    if (!ctx || !h_ms) return fail(M17GPU_ERR_ARG, "m17gpu_get_kernel_ms: bad argument");
+    double acc[4] = {0, 0, 0, 0};
+    int n[4] = {0, 0, 0, 0};
+    const size_t calls = ctx->ev_mode.size();
+    for (size_t k = 0; k < calls; ++k) {
+        hipEvent_t *ev = &ctx->ev_pool[5 * k];
+        const int last = ctx->ev_mode[k] == 1 ? 4 : 2;
+        HIPCHK(hipEventSynchronize(ev[last]));
+        for (int i = 0; i < last; ++i) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            acc[i] += ms; n[i]++;
+        }
+    }
+    for (int i = 0; i < 4; ++i) h_ms[i] = n[i] ? (float)(acc[i] / n[i]) : 0.0f;
+    if (h_calls) *h_calls = (int)calls;
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    ctx->ev_pool.clear();
+    ctx->ev_mode.clear();
     return M17GPU_OK;
 }
 
