@@ -1,0 +1,426 @@
+// m17_sync_wg.hip -- k_sync_frame_wg: timing recovery + sync correlator + framer
+// with one 256-thread WORKGROUP per channel (included by m17gpu_capi.hip after
+// m17_kernels.hip; same namespace, same helpers).
+//
+// Reference: m17_rx_sync_samples (m17_rx_sync.cpp:77-99) and m17_rx_sym
+// (m17_rx_frame.cpp:126-177).  The time axis of one channel is sequential only
+// through a handful of integers (m_clk, m_thr, m_index, lock state); the
+// arithmetic -- two 31-tap dot products per symbol instant -- depends on them
+// only through the polyphase branch m_index.  So for every 1920-sample block
+// all (up to 192) symbol instants are evaluated at once under the current
+// branch, one instant per thread, each thread keeping the reference's ascending
+// mul/add order; the early/late vote counter then becomes a popcount prefix over
+// four wave ballots and the first threshold crossing (rare once locked) cuts
+// the block and re-runs the remainder under the new branch.  While hunting
+// (threshold 10, a crossing every >= 11 instants) only one wave speculates.
+//
+// One workgroup barrier per pass: the ballots / filter outputs are double
+// buffered by pass parity and every wave scans all four ballots redundantly.
+//
+// LDS: both tap tables (2 x 40 x 32 floats), the block's input with its
+// 30-sample delay line twice (second copy shifted by one float so that every
+// (x[a], x[a+1]) pair is an aligned ds_read_b64 whatever the parity of a), the
+// symbol/frame buffers, and the cross-wave ballots.
+#pragma clang fp contract(off)
+
+namespace m17dev {
+
+constexpr int WG_T = 256;
+
+struct WgShared {
+    float mf[kPhases][32];
+    float md[kPhases][32];
+    float xa[kTaps - 1 + kDiscOut + 2];    // xa[i] = x[i]   (x[0..29] history, x[30..413] this block)
+    float xb[kTaps - 1 + kDiscOut + 2];    // xb[i] = x[i+1]
+    float sums[2][WG_T], difs[2][WG_T];
+    float h[8 + 264];                      // m_sync (8) followed by the block's symbols
+    float f[kFrameSyms];                   // m_f_sym
+    unsigned long long up[2][4], dn[2][4], hit[4];
+    float bc_var; int bc_type, bc_votes;
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+// vmcnt, i.e. it would wait for the prefetched next block and for every symbol /
+// record store at each barrier -- the threads exchange data through LDS only,
+// global memory is written for later kernels.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+#ifdef M17_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i) do { unsigned long long now_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    acc_[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+// The control state of a channel is wave-uniform by construction; telling the
+// compiler (readfirstlane) keeps it in SGPRs and the branches on the scalar unit
+// instead of EXEC-mask control flow.
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ int first_set4(const unsigned long long m[4])
+{
+    int k = -1;
+#pragma unroll
+    for (int w = 3; w >= 0; --w)
+        if (m[w]) k = 64 * w + __ffsll((long long)m[w]) - 1;
+    return k;
+}
+
+// m17_sync_check (m17_rx_frame.cpp:47-81) on ONE 8-symbol vector that every lane
+// of the calling wave holds: lane k < 6 accumulates template k, the in-order
+// strict-'>' argmax walks the six lanes with readlane, the votes are a ballot.
+__device__ __forceinline__ SyncResult sync_check_wave(const float v[8])
+{
+    constexpr unsigned negs[6] = {0xAA, 0xB0, 0x4F, 0xF2, 0x0D, 0x40};
+    const int lane = lane_id();
+    unsigned neg = negs[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) neg = (lane == k) ? negs[k] : neg;
+    float s = (neg & 1u) ? -v[0] : v[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s = (neg >> i & 1u) ? s - v[i] : s + v[i];
+    float best = 0.0f; int nmax = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float sk = bcast_lane(s, k);
+        if (sk > best) { best = sk; nmax = k; }
+    }
+    unsigned nm = negs[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) nm = (nmax == k) ? negs[k] : nm;
+    float mine = v[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mine = (lane == i) ? v[i] : mine;
+    const bool bad = (lane < 8) && ((nm >> lane & 1u) ? (mine > 0.0f) : (mine < 0.0f));
+    const int votes = __popcll(__ballot(bad));
+    float mmin = fabsf(v[0]), mmax = mmin;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        const float a = fabsf(v[i]);
+        if (a > mmax) mmax = a;
+        else if (a < mmin) mmin = a;
+    }
+    float var = (mmax - mmin) / mmax;
+    if (var != var) var = 1.0f;
+    SyncResult r; r.type = nmax; r.votes = votes; r.variance = var;
+    return r;
+}
+
+__global__ __launch_bounds__(WG_T, 4)     // 4 workgroups per CU (1,024 channels on 256 CUs): <= 128 VGPRs
+void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
+                     const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
+                     ChanState *__restrict__ st, int C, int nblk, int mode,
+                     m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
+                     float *__restrict__ syms, int32_t *__restrict__ nsyms,
+                     float *__restrict__ fsym, int32_t *__restrict__ work, int32_t *__restrict__ nwork)
+{
+    __shared__ __attribute__((aligned(16))) WgShared sh;
+    const int t = (int)threadIdx.x, w = t >> 6, lane = t & 63;
+    const int chan = (int)blockIdx.x;
+    ChanState &cs = st[chan];
+    m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
+
+    // ---- tables and state into LDS / uniform registers
+    for (int q = t; q < kPhases * 32; q += WG_T) {
+        (&sh.mf[0][0])[q] = (&c_tab.mf[0][0])[q];
+        (&sh.md[0][0])[q] = (&c_tab.md[0][0])[q];
+    }
+    int clk = uni(cs.clk), thr = uni(cs.thr), index = uni(cs.index);
+    float sum = unif(cs.sum), dif = unif(cs.dif);
+    int flock = uni(cs.flock), fclk = uni(cs.fclk), ferr = uni(cs.ferr);
+    uint32_t block_count = (uint32_t)uni((int)cs.block_count);
+    if (t < kTaps - 1) {
+        const float v = cs.buff[t + 1];
+        sh.xa[t] = v;
+        if (t >= 1) sh.xb[t - 1] = v;
+    }
+    if (t < 8) sh.h[t] = cs.sync[t];
+    if (t < kFrameSyms) sh.f[t] = cs.fsym[t];
+    int nrec = 0, sym_total = 0, par = 0;
+    const size_t sym_base = (size_t)chan * M17_SYM_STRIDE(nblk);
+    const float *dsrc = disc + (size_t)chan * nblk * kDiscOut;
+    const float *osrc = offs ? offs + (size_t)chan * nblk : nullptr;
+
+    // block 0 input (DC removed, m17_dsp.cpp:217-219)
+    {
+        const float off = osrc ? osrc[0] : 0.0f;
+        float v0 = dsrc[t];
+        float v1 = (t + WG_T < kDiscOut) ? dsrc[t + WG_T] : 0.0f;
+        if (osrc) { v0 = v0 - off; v1 = v1 - off; }
+        sh.xa[kTaps - 1 + t] = v0; sh.xb[kTaps - 2 + t] = v0;
+        if (t + WG_T < kDiscOut) { sh.xa[kTaps - 1 + t + WG_T] = v1; sh.xb[kTaps - 2 + t + WG_T] = v1; }
+    }
+    lds_barrier();
+
+#ifdef M17_STAMPS
+    unsigned long long acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, last_ = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    for (int b = 0; b < nblk; ++b) {
+        STAMP(0);
+        // prefetch the next block's input; it is committed to LDS at the end of this block
+        // (the DC subtraction is deferred to the commit so that nothing waits on these loads here)
+        float n0 = 0.0f, n1 = 0.0f, noff = 0.0f;
+        if (b + 1 < nblk) {
+            const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
+            noff = osrc ? osrc[b + 1] : 0.0f;
+            n0 = nx[t];
+            n1 = (t + WG_T < kDiscOut) ? nx[t + WG_T] : 0.0f;
+        }
+
+        // ---- timing recovery: x[i .. i+30] is the delay line at input i; symbols go to h[8+..]
+        const int thresh = flock ? 80 : 10;
+        const int width = flock ? WG_T : 64;
+        int p = 0, m_idx = 0;
+        while (p < kDiscOut) {
+            p = uni(p); m_idx = uni(m_idx); thr = uni(thr); index = uni(index); clk = uni(clk);
+            if (clk == 1) {
+                // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72)
+                clk = 0;
+                const float d = (sum < 0.0f) ? -dif : dif;
+                if (d > 0.0f) thr++;
+                if (d < 0.0f) thr--;
+                if (thr > thresh) {
+                    index = (index + 1) % kPhases; thr = 0;
+                    if (index == 0) { clk = 1; if (m_idx >= 0 && t == 0) sh.h[8 + m_idx] = 0.0f; m_idx++; }
+                }
+                if (thr < -thresh) {
+                    thr = 0; index = (index + kPhases - 1) % kPhases;
+                    if (index == kPhases - 1) { clk = 1; m_idx--; }
+                }
+                p++;
+                continue;
+            }
+            // one pass: thread k = filter tick at input p+2k and the vote tick after it
+            const int nf = min(width, (kDiscOut - p + 1) >> 1);
+            const int ik = p + 2 * t;
+            const bool have = t < nf;
+            float s = 0.0f, d = 0.0f;
+            if (w * 64 < nf) {                                  // wave-uniform: this wave has instants to evaluate
+                const int a = have ? ik : p;
+                const float *xs = (a & 1) ? (sh.xb + (a - 1)) : (sh.xa + a);
+                const float2 *xp = reinterpret_cast<const float2 *>(xs);
+                const float4 *mf4 = reinterpret_cast<const float4 *>(sh.mf[index]);   // broadcast reads
+                const float4 *md4 = reinterpret_cast<const float4 *>(sh.md[index]);
+                // 31 taps in four groups of 8 (last: 7); the next group's LDS reads are issued
+                // before the current group's strictly ordered mul/add chain (rx_sync_filter :25-31)
+                float4 ma = mf4[0], mb = mf4[1], da = md4[0], db = md4[1];
+                float2 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 nma = ma, nmb = mb, nda = da, ndb = db;
+                    float2 y0 = x0, y1 = x1, y2 = x2, y3 = x3;
+                    if (g < 3) {
+                        nma = mf4[2 * g + 2]; nmb = mf4[2 * g + 3]; nda = md4[2 * g + 2]; ndb = md4[2 * g + 3];
+                        y0 = xp[4 * g + 4]; y1 = xp[4 * g + 5]; y2 = xp[4 * g + 6];
+                        if (g < 2) y3 = xp[4 * g + 7];
+                        else { y3.x = xs[30]; y3.y = 0.0f; }
+                    }
+                    if (g == 0) { s = x0.x * ma.x; d = x0.x * da.x; }    // bare first product
+                    else        { s += x0.x * ma.x; d += x0.x * da.x; }
+                    s += x0.y * ma.y; d += x0.y * da.y;
+                    s += x1.x * ma.z; d += x1.x * da.z;
+                    s += x1.y * ma.w; d += x1.y * da.w;
+                    s += x2.x * mb.x; d += x2.x * db.x;
+                    s += x2.y * mb.y; d += x2.y * db.y;
+                    s += x3.x * mb.z; d += x3.x * db.z;
+                    if (g < 3) { s += x3.y * mb.w; d += x3.y * db.w; }   // tap 31 does not exist
+                    ma = nma; mb = nmb; da = nda; db = ndb;
+                    x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+                }
+            }
+            STAMP(1);
+            sh.sums[par][t] = s; sh.difs[par][t] = d;
+            const bool vote_ok = have && (ik + 1 < kDiscOut);
+            const float dd = (s < 0.0f) ? -d : d;
+            const unsigned long long upm = __ballot(vote_ok && dd > 0.0f);
+            const unsigned long long dnm = __ballot(vote_ok && dd < 0.0f);
+            if (lane == 0) { sh.up[par][w] = upm; sh.dn[par][w] = dnm; }
+            lds_barrier();
+            STAMP(2);
+            // every wave scans all four ballots: lane = position inside a 64-instant segment
+            const unsigned long long incl = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+            int running = thr, kstar = -1, ts = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned long long Uq = uni64(sh.up[par][q]), Dq = uni64(sh.dn[par][q]);
+                if (q * 64 < nf) {
+                    const int tk = running + __popcll(Uq & incl) - __popcll(Dq & incl);
+                    const int idx = q * 64 + lane;
+                    const bool ok = (idx < nf) && (p + 2 * idx + 1 < kDiscOut);
+                    const unsigned long long cr = __ballot(ok && (tk > thresh || tk < -thresh));
+                    if (kstar < 0 && cr) {
+                        const int kl = __ffsll((long long)cr) - 1;
+                        kstar = q * 64 + kl;
+                        ts = bcast_lane_i(tk, kl);
+                    }
+                    running += (int)__popcll(Uq) - (int)__popcll(Dq);
+                }
+            }
+            const int naccept = (kstar >= 0) ? kstar + 1 : nf;
+            if (t < naccept && (m_idx + t) >= 0) sh.h[8 + m_idx + t] = s;
+            m_idx += naccept;
+            sum = unif(sh.sums[par][naccept - 1]);
+            dif = unif(sh.difs[par][naccept - 1]);
+            if (kstar >= 0) {
+                thr = 0; clk = 0;
+                if (ts > thresh) {
+                    index = (index + 1) % kPhases;
+                    if (index == 0) { clk = 1; if (m_idx >= 0 && t == 0) sh.h[8 + m_idx] = 0.0f; m_idx++; }
+                } else {
+                    index = (index + kPhases - 1) % kPhases;
+                    if (index == kPhases - 1) { clk = 1; m_idx--; }
+                }
+                p = p + 2 * kstar + 2;
+            } else {
+                thr = running;
+                const int ilast = p + 2 * (nf - 1);
+                if (ilast + 1 < kDiscOut) { clk = 0; p = ilast + 2; }
+                else { clk = 1; p = kDiscOut; }
+            }
+            par ^= 1;
+            STAMP(3);
+        }
+        const int n = m_idx > 0 ? m_idx : 0;
+        lds_barrier();
+        STAMP(4);
+
+        // symbols out (optional)
+        if (syms && t < n) syms[sym_base + sym_total + t] = sh.h[8 + t];
+        if (nsyms && t == 0) nsyms[(size_t)chan * nblk + b] = n;
+        sym_total += n;
+
+        // ---- framer (m17_rx_frame.cpp:126-177)
+        int pos = 0;
+        while (pos < n) {
+            if (flock) {
+                const int cnt = min(kFrameSyms - fclk, n - pos);
+                if (t < cnt) sh.f[fclk + t] = sh.h[8 + pos + t];
+                fclk += cnt; pos += cnt;
+                if (fclk == kFrameSyms) {
+                    fclk = 0;
+                    lds_barrier();
+                    // classify the frame by its own leading sync word: one wave computes, all read
+                    if (w == 0) {
+                        float v[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = sh.f[i];
+                        const SyncResult r0 = sync_check_wave(v);
+                        if (lane == 0) { sh.bc_type = r0.type; sh.bc_votes = r0.votes; sh.bc_var = r0.variance; }
+                    }
+                    lds_barrier();
+                    SyncResult r;
+                    r.type = uni(sh.bc_type); r.votes = uni(sh.bc_votes); r.variance = unif(sh.bc_var);
+                    uint32_t flags = 0;
+                    bool parse = false, unlock = false;
+                    if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
+                    else if (sync_accept(r, true)) { flags |= M17_F_SYNC_OK; parse = true; ferr = 0; }
+                    else {
+                        ferr++;
+                        if (ferr > 5) { flags |= M17_F_LOST; unlock = true; }
+                        else parse = true;
+                    }
+                    if (parse && mode == 1) flags |= M17_F_PARSED;
+                    const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
+                    if (w == 0)
+                        emit_record(crecs, rec_cap, nrec, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
+                    if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
+                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kFrameSyms;
+                        if (t < kFrameSyms) fd[t] = sh.f[t];
+                        if (t == 0) work[atomicAdd(nwork, 1)] = chan * rec_cap + nrec;
+                    }
+                    nrec++;
+                    if (unlock) {
+                        flock = 0;
+                        // reset_sync(): the next hunt windows must see zeros behind them
+                        if (t < 8) { sh.h[pos + t] = 0.0f; cs.sync[t] = 0.0f; }
+                    }
+                    lds_barrier();
+                }
+            } else {
+                // hunt: candidate j = pos+t, window = m_sync after shifting symbol j in
+                const int j = pos + t;
+                const bool cand = j < n;
+                const int jj = cand ? j : pos;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = sh.h[jj + 1 + i];
+                const SyncResult r = sync_check(v);
+                const unsigned long long hm = __ballot(cand && sync_accept(r, false));
+                if (lane == 0) sh.hit[w] = hm;
+                lds_barrier();
+                unsigned long long H[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) H[q] = uni64(sh.hit[q]);
+                const int l = first_set4(H);
+                if (l >= 0) {
+                    const int js = pos + l;
+                    if (t == l) { sh.bc_type = r.type; sh.bc_votes = r.votes; sh.bc_var = r.variance; }
+                    // copy_sync(); m_fclk = 8; lock; m17_aos()
+                    float wv = 0.0f;
+                    if (t < 8) wv = sh.h[js + 1 + t];
+                    lds_barrier();
+                    if (t < 8) { sh.f[t] = wv; cs.sync[t] = wv; }
+                    fclk = 8; ferr = 0; flock = 1;
+                    if (w == 0)
+                        emit_record(crecs, rec_cap, nrec, (uint32_t)uni(sh.bc_type) | ((uint32_t)uni(sh.bc_votes) << 8),
+                                    M17_F_AOS, unif(sh.bc_var), block_count, (uint32_t)js);
+                    nrec++;
+                    pos = js + 1;
+                } else {
+                    pos = min(n, pos + WG_T);
+                }
+                lds_barrier();
+            }
+        }
+        STAMP(5);
+        // m_sync for the next block while hunting: last 8 entries of h;
+        // delay line for the next block: last 30 inputs; then commit the prefetched input
+        {
+            float keep_h = 0.0f, keep_x = 0.0f;
+            if (t < 8) keep_h = sh.h[n + t];
+            if (t < kTaps - 1) keep_x = sh.xa[kDiscOut + t];
+            lds_barrier();
+            if (!flock && t < 8) { sh.h[t] = keep_h; cs.sync[t] = keep_h; }
+            if (t < kTaps - 1) {
+                sh.xa[t] = keep_x;
+                if (t >= 1) sh.xb[t - 1] = keep_x;
+            }
+            if (b + 1 < nblk) {
+                if (osrc) { n0 = n0 - noff; n1 = n1 - noff; }     // out[i] - offset (m17_dsp.cpp:217-219)
+                sh.xa[kTaps - 1 + t] = n0; sh.xb[kTaps - 2 + t] = n0;
+                if (t + WG_T < kDiscOut) { sh.xa[kTaps - 1 + t + WG_T] = n1; sh.xb[kTaps - 2 + t + WG_T] = n1; }
+            }
+        }
+        block_count++;
+        lds_barrier();
+        STAMP(6);
+    }
+#ifdef M17_STAMPS
+    if (chan == 0 && t == 0) for (int i = 0; i < 12; ++i) g_stamps[i] = acc_[i];
+#endif
+
+    // ---- store state
+    if (t == 0) {
+        cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum; cs.dif = dif;
+        cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count;
+        cs.buff[0] = 0.0f;
+        if (counts) counts[chan] = nrec;
+    }
+    if (t < kTaps - 1) cs.buff[t + 1] = sh.xa[t];
+    if (t < kFrameSyms) cs.fsym[t] = sh.f[t];
+}
+
+} // namespace m17dev

@@ -1,12 +1,14 @@
 // m17gpu_capi.hip -- the C-ABI of include/m17gpu.h on top of the gfx950 kernels.
 // No CPU fallback: every compute entry point needs a HIP device.
 #include "m17_kernels.hip"
+#include "m17_sync_wg.hip"
 #include "m17_host.h"
 #include "../../include/m17gpu.h"
 #include <string>
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include <new>
 
 using namespace m17dev;
@@ -23,6 +25,7 @@ struct m17gpu_ctx {
     int32_t *d_work = nullptr, *d_nwork = nullptr, *d_counts = nullptr;
     uint16_t *d_genc = nullptr, *d_gerr = nullptr;
     bool profiling = false;
+    int sync_impl = 1;                       // 1 = workgroup per channel (default), 0 = wave per channel
     std::vector<hipEvent_t> ev_pool;         // 5 events per profiled call
     std::vector<int> ev_mode;                // mode of each profiled call
 };
@@ -86,11 +89,18 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
                       m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, float *d_syms, int32_t *d_nsyms,
                       hipStream_t st)
 {
-    hipLaunchKernelGGL(k_sync_frame, dim3(cdiv(ctx->C, SF_WAVES)), dim3(64 * SF_WAVES), 0, st,
-                       disc, offs, ctx->d_state, ctx->C, nblk, mode,
-                       reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
-                       d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
-                       ctx->d_fsym, ctx->d_work, ctx->d_nwork);
+    if (ctx->sync_impl == 1)
+        hipLaunchKernelGGL(k_sync_frame_wg, dim3(ctx->C), dim3(WG_T), 0, st,
+                           disc, offs, ctx->d_state, ctx->C, nblk, mode,
+                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
+                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
+                           ctx->d_fsym, ctx->d_work, ctx->d_nwork);
+    else
+        hipLaunchKernelGGL(k_sync_frame, dim3(cdiv(ctx->C, SF_WAVES)), dim3(64 * SF_WAVES), 0, st,
+                           disc, offs, ctx->d_state, ctx->C, nblk, mode,
+                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
+                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
+                           ctx->d_fsym, ctx->d_work, ctx->d_nwork);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -120,6 +130,7 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     if (!ctx) return fail(M17GPU_ERR_NOMEM, "m17gpu_create: out of host memory");
     ctx->device = device; ctx->C = n_channels; ctx->max_blocks = max_blocks;
     ctx->rec_cap_max = 2 * max_blocks + 2;
+    if (const char *e = std::getenv("M17GPU_SYNC_IMPL")) ctx->sync_impl = (std::strcmp(e, "w64") == 0) ? 0 : 1;
     const size_t cb = (size_t)n_channels * max_blocks;
     int rc = upload_tables(ctx);
     if (rc != M17GPU_OK) { m17gpu_destroy(ctx); return rc; }
@@ -170,11 +181,11 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
 {
     if (!ctx || !d_iq || nblk <= 0 || nblk > ctx->max_blocks || rec_cap < 0)
         return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: bad argument (nblk must be 1..max_blocks)");
-    if (mode == 1 && (!d_recs || rec_cap <= 0 || rec_cap > ctx->rec_cap_max))
+    if ((mode & 0xFF) == 1 && (!d_recs || rec_cap <= 0 || rec_cap > ctx->rec_cap_max))
         return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: mode 1 needs d_recs and 0 < rec_cap <= 2*max_blocks+2");
     hipStream_t st = S(stream);
     int rc;
-    if (mode == 1) HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t), st));
+    if ((mode & 0xFF) == 1) HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t), st));
     hipEvent_t *ev = nullptr;
     if (ctx->profiling && ctx->ev_mode.size() < 512) {
         const size_t base = ctx->ev_pool.size();
@@ -183,7 +194,7 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
             HIPCHK(hipEventCreate(&e));
             ctx->ev_pool.push_back(e);
         }
-        ctx->ev_mode.push_back(mode);
+        ctx->ev_mode.push_back(mode & 0xFF);
         ev = &ctx->ev_pool[base];
     }
 #define MARK(i) do { if (ev) HIPCHK(hipEventRecord(ev[i], st)); } while (0)
@@ -193,7 +204,7 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
     if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
                                 d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
     MARK(2);
-    if (mode == 1) {
+    if ((mode & 0xFF) == 1) {
         const long long slots = (long long)ctx->C * rec_cap;
         int grid = cdiv(slots, DEC_FRAMES_PER_WG);
         if (grid > 4096) grid = 4096;
@@ -211,6 +222,15 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
 #undef MARK
     return M17GPU_OK;
 }
+
+#ifdef M17_STAMPS
+int m17gpu_debug_stamps(unsigned long long *out)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16));
+    return 0;
+}
+#endif
 
 int m17gpu_set_profiling(m17gpu_ctx *ctx, int on)
 {
