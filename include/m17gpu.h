@@ -130,6 +130,13 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
 int m17gpu_set_profiling(m17gpu_ctx *ctx, int on);
 int m17gpu_get_kernel_ms(m17gpu_ctx *ctx, float h_ms[4], int *h_calls);
 
+/* Exhaustive on-device equivalence check of the front end's shortened exact
+ * arithmetic (int16 scaling of m17_dsp.cpp:136-141, sqrt and reciprocal of
+ * dsp_limit :412-419) against the literal fp64 / IEEE expressions.
+ * h_bad[4] = mismatches of {scale, sqrt, reciprocal, composed limiter}; all 0
+ * is required for the bit-exactness claim.  Synchronous, ~0.1 s. */
+int m17gpu_selftest(m17gpu_ctx *ctx, unsigned *h_bad);
+
 /* ---------------- state access (host, synchronous) ---------------- */
 /* the reassembled LSF pair m_lsf[2][30] of each channel (m17_rx_parse.cpp:5) */
 int m17gpu_get_lsf(m17gpu_ctx *ctx, uint8_t *h_lsf /* [C][2][30] */);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "m17gpu_golay_decode": (_i, [_vp, _vp, _vp, _i, _vp]),
     "m17gpu_set_profiling": (_i, [_vp, _i]),
     "m17gpu_get_kernel_ms": (_i, [_vp, _vp, _vp]),
+    "m17gpu_selftest": (_i, [_vp, _vp]),
     "m17gpu_get_lsf": (_i, [_vp, _vp]),
     "m17gpu_get_counters": (_i, [_vp, _vp]),
     "m17gpu_get_lock": (_i, [_vp, _vp]),

@@ -140,6 +140,12 @@ class Receiver:
         _check(lib().m17gpu_get_kernel_ms(self._ctx, ms, C.byref(n)), "m17gpu_get_kernel_ms")
         return list(ms), n.value
 
+    def selftest(self):
+        """Mismatch counts of the exhaustive exact-arithmetic self test (must be all zero)."""
+        bad = (C.c_uint * 4)()
+        _check(lib().m17gpu_selftest(self._ctx, bad), "m17gpu_selftest")
+        return list(bad)
+
     # ---- state -------------------------------------------------------------
     def lsf(self):
         a = np.zeros((self.C, 2, 30), np.uint8)

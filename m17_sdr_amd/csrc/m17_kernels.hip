@@ -26,6 +26,7 @@
 // -ffp-contract=off and WITHOUT -ffast-math.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <type_traits>
 #include "m17_dev.h"
 
 #pragma clang fp contract(off)
@@ -47,18 +48,111 @@ __device__ __forceinline__ int bcast_lane_i(int v, int src) { return __builtin_a
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
+// ---- exact arithmetic of the front end -------------------------------------
+// Two implementations of each step: *_ref follows the reference expression
+// literally (fp64 where the reference promotes, compiler-generated IEEE sqrt and
+// divide); the default one is a shorter instruction sequence that returns the
+// SAME bits.  k_selftest_* compares them exhaustively over the whole input
+// domain on the device (m17gpu_selftest; run by tests/test_gpu_parity.py).
+
 // dsp_short_to_float (m17_dsp.cpp:136-141): (float)((double)x * 0.00003)
-__device__ __forceinline__ float s16_to_float(int x) { return (float)((double)x * 0.00003); }
+__device__ __forceinline__ float s16_to_float_ref(int x) { return (float)((double)x * 0.00003); }
+// 0.00003 = CHI + CLO + 2.4e-20 with CHI = (float)0.00003.  fma(x, CHI, RN(x*CLO))
+// equals the double-rounded reference for every int16 x (65,536 cases, verified
+// on the host at build-test time and on the device by the self test).
+__device__ __forceinline__ float s16_to_float(int x)
+{
+    const float xf = (float)x;
+    return __builtin_fmaf(xf, 0x1.f75104p-16f, xf * 0x1.aaa3aep-41f);
+}
+
+// correctly rounded sqrt for normal, finite a (here 9e-10 <= a <= 2, or a == 0):
+// v_sqrt_f32 is within 1 ulp; choose among {s-1ulp, s, s+1ulp} by the sign of the
+// exact residuals -- the compiler's own IEEE lowering without its denormal
+// pre-scaling and class fix-ups.  a == 0 falls through with s = 0 (residuals NaN).
+__device__ __forceinline__ float sqrt_rn_normal(float a)
+{
+    const float s = __builtin_amdgcn_sqrtf(a);
+    const float sm = __int_as_float(__float_as_int(s) - 1);
+    const float sp = __int_as_float(__float_as_int(s) + 1);
+    const float rm = __builtin_fmaf(-sm, s, a);
+    const float rp = __builtin_fmaf(-sp, s, a);
+    float r = (rm <= 0.0f) ? sm : s;
+    r = (rp > 0.0f) ? sp : r;
+    return r;
+}
+
+// correctly rounded 1/m for normal m away from the exponent limits: one
+// Newton-Raphson step on v_rcp_f32 (1 ulp), both operations fused.
+__device__ __forceinline__ float rcp_rn_normal(float m)
+{
+    const float r0 = __builtin_amdgcn_rcpf(m);
+    const float e = __builtin_fmaf(-m, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
 
 // dsp_limit (m17_dsp.cpp:412-419): m = sqrtf(re^2+im^2); g = (float)(1.0/m).
 // (float)(1.0/(double)m) == correctly rounded 1.0f/m (double rounding is
 // innocuous for division at 53 >= 2*24+2 bits), so fp32 IEEE divide is used.
-__device__ __forceinline__ void limit(float &re, float &im)
+__device__ __forceinline__ void limit_ref(float &re, float &im)
 {
     const float m = __builtin_sqrtf(re * re + im * im);   // IEEE-correct under -fhip-fp32-correctly-rounded-divide-sqrt
     const float g = 1.0f / m;
     re = re * g;
     im = im * g;
+}
+__device__ __forceinline__ void limit(float &re, float &im)
+{
+#ifdef M17_REF_ARITH
+    limit_ref(re, im);
+#else
+    const float m = sqrt_rn_normal(re * re + im * im);
+    const float g = rcp_rn_normal(m);
+    re = re * g;
+    im = im * g;
+#endif
+}
+
+// exhaustive device-side equivalence checks of the sequences above
+__global__ void k_selftest_scale(unsigned *bad)
+{
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 32768;
+    if (x > 32767) return;
+    const float a = s16_to_float(x), b = s16_to_float_ref(x);
+    if (__float_as_uint(a) != __float_as_uint(b)) atomicAdd(bad, 1u);
+}
+__global__ void k_selftest_sqrt(unsigned lo, unsigned hi, unsigned *bad)
+{
+    for (unsigned long long u = lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u <= hi;
+         u += (unsigned long long)gridDim.x * blockDim.x) {
+        const float a = __uint_as_float((unsigned)u);
+        const float f = sqrt_rn_normal(a), r = __builtin_sqrtf(a);
+        if (__float_as_uint(f) != __float_as_uint(r) && !(f != f && r != r)) atomicAdd(bad, 1u);
+    }
+}
+__global__ void k_selftest_rcp(unsigned lo, unsigned hi, unsigned *bad)
+{
+    for (unsigned long long u = lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u <= hi;
+         u += (unsigned long long)gridDim.x * blockDim.x) {
+        const float m = __uint_as_float((unsigned)u);
+        const float f = rcp_rn_normal(m), r = 1.0f / m;
+        if (__float_as_uint(f) != __float_as_uint(r) && !(f != f && r != r)) atomicAdd(bad, 1u);
+    }
+}
+// the composed limiter on every int16 pair of a coarse lattice plus all pairs near zero
+__global__ void k_selftest_limit(unsigned *bad)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;     // 2^26 cases
+    int xr, xi;
+    if (i < (1u << 24)) { xr = (int)(i & 0xFFF) * 16 - 32768 + 7; xi = (int)(i >> 12) * 16 - 32768 + 3; }
+    else { const unsigned j = i - (1u << 24); xr = (int)(j & 0x1FFF) - 4096; xi = (int)((j >> 13) & 0x1FFF) - 4096; if (j >= (1u << 26)) return; }
+    if (i >= (1u << 24) + (1u << 26)) return;
+    float ar = s16_to_float(xr), ai = s16_to_float(xi), br = s16_to_float_ref(xr), bi = s16_to_float_ref(xi);
+    limit(ar, ai);
+    limit_ref(br, bi);
+    const bool same = (__float_as_uint(ar) == __float_as_uint(br) || (ar != ar && br != br)) &&
+                      (__float_as_uint(ai) == __float_as_uint(bi) || (ai != ai && bi != bi));
+    if (!same) atomicAdd(bad, 1u);
 }
 
 // ---------------------------------------------------------------------------
@@ -170,6 +264,173 @@ void k_frontend(const uint4 *__restrict__ iq,        // [total][480] uint4 (4 IQ
         offs[cb] = offset / (float)kBlockSamples;     // offset/len (m17_dsp.cpp:213)
         if (update_state && blk == nblk - 1) {
             st[chan].z0re = z0re; st[chan].z0im = z0im; st[chan].z1re = z1re; st[chan].z1im = z1im;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_frontend_q: the same stage with FOUR lanes per (channel, block), 16 per wave.
+// Used when there are too few channel-blocks to fill the chip with one lane each
+// (51,200 channel-blocks = 800 waves of k_frontend = 0.8 waves per SIMD).
+//   load   : the wave fetches a [16 rows][64 samples] tile with 16 lanes per row,
+//            i.e. 256 contiguous bytes per row per load instruction (measured:
+//            6.4 TB/s for this pattern vs 3.6 TB/s for 16-byte pieces), one chunk
+//            ahead in registers, staged through LDS;
+//   compute: lane (row, sub) converts, limits and discriminates its 16 consecutive
+//            samples; the two preceding limited samples come from the neighbour
+//            lane by DPP (quad carry for sub 0);
+//   sum    : only the DC sum is a chain: the u*0.5 values go back into the same LDS
+//            tile and lane sub==0 of each quad adds them in sample order, picking
+//            every 5th into an output tile that the quad stores as 256-byte rows.
+// ---------------------------------------------------------------------------
+constexpr int FQ_CHUNK  = 64;
+constexpr int FQ_STRIDE = 68;              // 64 + 4 dwords (68 = 4*17): conflict-free b128 for all three access shapes
+constexpr int FQ_WAVES  = 4;
+constexpr int FQ_NCHUNK = kBlockSamples / FQ_CHUNK;   // 30
+
+__device__ __forceinline__ float dpp_row_shr1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_quad_b3(float v)      // broadcast lane 3 of every quad
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xFF, 0xF, 0xF, true));
+}
+
+template <int C5>
+__device__ __forceinline__ void fq_sum_chunk(const float *row, float &offset, float *orow)
+{
+#pragma unroll
+    for (int q = 0; q < FQ_CHUNK / 4; ++q) {
+        const float4 v = reinterpret_cast<const float4 *>(row)[q];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pos = C5 * FQ_CHUNK + q * 4 + k;      // position inside the 320-sample period
+            offset += e[k];                                  // strictly sequential DC sum (m17_dsp.cpp:211)
+            if (pos % 5 == 4) orow[pos / 5] = e[k];          // count%5==0 pick (m17_dsp.cpp:207-210)
+        }
+    }
+}
+
+template <int ABL>      // ABL != 0: timing-only ablations (wrong results), see scripts/exp_fe.py
+__global__ __launch_bounds__(64 * FQ_WAVES)
+void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
+                  float *__restrict__ disc_raw, float *__restrict__ offs,
+                  int nblk, int total, int update_state)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[FQ_WAVES][16 * FQ_STRIDE];  // raw IQ, then u*0.5
+    __shared__ __attribute__((aligned(16))) float otile[FQ_WAVES][16 * FQ_STRIDE];    // 64 picked outputs per row
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int cbl = lane >> 2, sub = lane & 3;
+    const int cb0 = ((int)blockIdx.x * FQ_WAVES + wave) * 16;
+    if (cb0 >= total) return;
+    const bool valid = (cb0 + cbl) < total;
+    const int cb = valid ? cb0 + cbl : total - 1;
+    const int chan = cb / nblk, blk = cb - chan * nblk;
+    uint32_t *my = tile[wave];
+    float *myf = reinterpret_cast<float *>(tile[wave]);
+    float *myo = otile[wave];
+
+    // z[0], z[1] at the start of the block, identical in the four lanes of a quad
+    float c0re, c0im, c1re, c1im;
+    if (blk == 0) {
+        c0re = st[chan].z0re; c0im = st[chan].z0im; c1re = st[chan].z1re; c1im = st[chan].z1im;
+    } else {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(iq) + (size_t)cb * kBlockSamples;
+        const uint32_t a = p[-2], b = p[-1];
+        c1re = s16_to_float((int)(short)(a & 0xFFFF)); c1im = s16_to_float((int)a >> 16);
+        c0re = s16_to_float((int)(short)(b & 0xFFFF)); c0im = s16_to_float((int)b >> 16);
+        limit(c1re, c1im);
+        limit(c0re, c0im);
+    }
+
+    // cooperative tile load: instruction j covers rows 4j..4j+3, 16 lanes x 16 B = 256 B per row
+    // (named scalars, not arrays: the chunk body is a lambda and captured arrays end up in scratch)
+    const int lr = lane >> 4, c16 = lane & 15;
+    auto row_ptr = [&](int j) {
+        int row = cb0 + j * 4 + lr; row = row < total ? row : total - 1;
+        return iq + (size_t)row * (kBlockSamples / 4) + c16;
+    };
+    const uint4 *g0 = row_ptr(0), *g1 = row_ptr(1), *g2 = row_ptr(2), *g3 = row_ptr(3);
+    const int l0 = lr * FQ_STRIDE + c16 * 4, l1 = l0 + 4 * FQ_STRIDE, l2 = l0 + 8 * FQ_STRIDE, l3 = l0 + 12 * FQ_STRIDE;
+    uint4 s0 = g0[0], s1 = g1[0], s2 = g2[0], s3 = g3[0];
+
+    float offset = 0.0f;
+    float *dst = disc_raw + (size_t)cb * kDiscOut;
+
+    auto chunk_body = [&](int chunk, auto c5tag) {
+        constexpr int C5 = decltype(c5tag)::value;
+        // raw tile in, next chunk's loads out
+        *reinterpret_cast<uint4 *>(&my[l0]) = s0;
+        *reinterpret_cast<uint4 *>(&my[l1]) = s1;
+        *reinterpret_cast<uint4 *>(&my[l2]) = s2;
+        *reinterpret_cast<uint4 *>(&my[l3]) = s3;
+        if (!(ABL & 4)) {
+            const int nx = ((chunk + 1 < FQ_NCHUNK) ? chunk + 1 : chunk) * (FQ_CHUNK / 4);
+            s0 = g0[nx]; s1 = g1[nx]; s2 = g2[nx]; s3 = g3[nx];
+        }
+        wave_lds_sync();
+        uint32_t w[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&my[cbl * FQ_STRIDE + sub * 16 + q * 4]);
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+        wave_lds_sync();                                       // every lane holds its samples: the tile is free
+        float pre[16], pim[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            pre[e] = s16_to_float((int)(short)(w[e] & 0xFFFF));
+            pim[e] = s16_to_float((int)w[e] >> 16);
+            if (!(ABL & 2)) limit(pre[e], pim[e]);
+        }
+        // the two samples in front of this lane's run: neighbour lane, or the carry for sub 0
+        float p0re = dpp_row_shr1(pre[15]), p0im = dpp_row_shr1(pim[15]);
+        float p1re = dpp_row_shr1(pre[14]), p1im = dpp_row_shr1(pim[14]);
+        if (sub == 0) { p0re = c0re; p0im = c0im; p1re = c1re; p1im = c1im; }
+        c0re = dpp_quad_b3(pre[15]); c0im = dpp_quad_b3(pim[15]);
+        c1re = dpp_quad_b3(pre[14]); c1im = dpp_quad_b3(pim[14]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float uh[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = 4 * q + k;
+                // dsp_arctan_disc2 (m17_dsp.cpp:194-222): z0 = sample e-1, z1 = sample e-2
+                const float z0re = (e >= 1) ? pre[e >= 1 ? e - 1 : 0] : p0re, z0im = (e >= 1) ? pim[e >= 1 ? e - 1 : 0] : p0im;
+                const float z1re = (e >= 2) ? pre[e >= 2 ? e - 2 : 0] : (e == 1 ? p0re : p1re);
+                const float z1im = (e >= 2) ? pim[e >= 2 ? e - 2 : 0] : (e == 1 ? p0im : p1im);
+                const float aa = z0im * (pre[e] - z1re);
+                const float bb = z0re * (pim[e] - z1im);
+                uh[k] = (bb - aa) * 0.5f;
+            }
+            *reinterpret_cast<float4 *>(&myf[cbl * FQ_STRIDE + sub * 16 + q * 4]) = make_float4(uh[0], uh[1], uh[2], uh[3]);
+        }
+        wave_lds_sync();
+        if (!(ABL & 1)) { if (sub == 0) fq_sum_chunk<C5>(&myf[cbl * FQ_STRIDE], offset, &myo[cbl * FQ_STRIDE]); }
+        else { offset += myf[cbl * FQ_STRIDE + sub]; myo[cbl * FQ_STRIDE + C5] = offset; }
+        wave_lds_sync();
+    };
+
+    for (int it = 0; it < FQ_NCHUNK / 5; ++it) {
+        chunk_body(it * 5 + 0, std::integral_constant<int, 0>{});
+        chunk_body(it * 5 + 1, std::integral_constant<int, 1>{});
+        chunk_body(it * 5 + 2, std::integral_constant<int, 2>{});
+        chunk_body(it * 5 + 3, std::integral_constant<int, 3>{});
+        chunk_body(it * 5 + 4, std::integral_constant<int, 4>{});
+        // 64 outputs per row: the quad stores its row's 256 bytes
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(&myo[cbl * FQ_STRIDE + q * 16 + sub * 4]);
+            if (valid) *reinterpret_cast<float4 *>(dst + it * 64 + q * 16 + sub * 4) = v;
+        }
+        wave_lds_sync();
+    }
+    if (sub == 0 && valid) {
+        offs[cb] = offset / (float)kBlockSamples;
+        if (update_state && blk == nblk - 1) {
+            st[chan].z0re = c0re; st[chan].z0im = c0im; st[chan].z1re = c1re; st[chan].z1im = c1im;
         }
     }
 }

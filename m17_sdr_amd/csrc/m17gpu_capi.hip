@@ -25,6 +25,7 @@ struct m17gpu_ctx {
     int32_t *d_work = nullptr, *d_nwork = nullptr, *d_counts = nullptr;
     uint16_t *d_genc = nullptr, *d_gerr = nullptr;
     bool profiling = false;
+    int fe_impl = 0;                         // 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block
     int sync_impl = 1;                       // 1 = workgroup per channel (default), 0 = wave per channel
     std::vector<hipEvent_t> ev_pool;         // 5 events per profiled call
     std::vector<int> ev_mode;                // mode of each profiled call
@@ -79,8 +80,20 @@ int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc,
                     int update_state, hipStream_t st)
 {
     const int total = ctx->C * nblk;
-    hipLaunchKernelGGL(k_frontend, dim3(cdiv(total, 64 * FE_WAVES)), dim3(64 * FE_WAVES), 0, st,
-                       reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, disc, offs, nblk, total, update_state);
+    // one lane per channel-block needs >= ~2 waves per SIMD to run at rate: 131,072 channel-blocks
+    const bool quad = ctx->fe_impl == 2 || ctx->fe_impl >= 100 || (ctx->fe_impl == 0 && total < 131072);
+#define LAUNCH_FQ(ABL) hipLaunchKernelGGL(k_frontend_q<ABL>, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st, \
+                           reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, disc, offs, nblk, total, update_state)
+    if (ctx->fe_impl >= 100) {          // timing-only ablations of k_frontend_q (results are wrong)
+        switch (ctx->fe_impl - 100) {
+        case 1: LAUNCH_FQ(1); break; case 2: LAUNCH_FQ(2); break; case 3: LAUNCH_FQ(3); break;
+        case 4: LAUNCH_FQ(4); break; case 7: LAUNCH_FQ(7); break; default: LAUNCH_FQ(0); break;
+        }
+    } else if (quad)
+        LAUNCH_FQ(0);
+    else
+        hipLaunchKernelGGL(k_frontend, dim3(cdiv(total, 64 * FE_WAVES)), dim3(64 * FE_WAVES), 0, st,
+                           reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, disc, offs, nblk, total, update_state);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -130,6 +143,7 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     if (!ctx) return fail(M17GPU_ERR_NOMEM, "m17gpu_create: out of host memory");
     ctx->device = device; ctx->C = n_channels; ctx->max_blocks = max_blocks;
     ctx->rec_cap_max = 2 * max_blocks + 2;
+    if (const char *e = std::getenv("M17GPU_FE_IMPL")) ctx->fe_impl = std::atoi(e);
     if (const char *e = std::getenv("M17GPU_SYNC_IMPL")) ctx->sync_impl = (std::strcmp(e, "w64") == 0) ? 0 : 1;
     const size_t cb = (size_t)n_channels * max_blocks;
     int rc = upload_tables(ctx);
@@ -231,6 +245,29 @@ int m17gpu_debug_stamps(unsigned long long *out)
     return 0;
 }
 #endif
+
+// Exhaustive on-device check that the shortened exact-arithmetic sequences of the
+// front end (int16 scaling, sqrt, reciprocal, composed limiter) return the same
+// bits as the literal reference expressions.  h_bad[4] = mismatch counts.
+int m17gpu_selftest(m17gpu_ctx *ctx, unsigned *h_bad)
+{
+    if (!ctx || !h_bad) return fail(M17GPU_ERR_ARG, "m17gpu_selftest: bad argument");
+    unsigned *d_bad = nullptr;
+    HIPCHK(hipMalloc(&d_bad, 4 * sizeof(unsigned)));
+    HIPCHK(hipMemset(d_bad, 0, 4 * sizeof(unsigned)));
+    hipLaunchKernelGGL(k_selftest_scale, dim3(256), dim3(256), 0, nullptr, d_bad + 0);
+    // a = re^2 + im^2 lies in [9e-10, 2]; sweep every float in [2^-32, 8) and zero
+    hipLaunchKernelGGL(k_selftest_sqrt, dim3(4096), dim3(256), 0, nullptr, 0x2F800000u, 0x41000000u, d_bad + 1);
+    hipLaunchKernelGGL(k_selftest_sqrt, dim3(1), dim3(64), 0, nullptr, 0u, 0u, d_bad + 1);
+    // m = sqrt(a) lies in [3e-5, 1.42]; sweep every float in [2^-17, 4)
+    hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(256), 0, nullptr, 0x37000000u, 0x40800000u, d_bad + 2);
+    hipLaunchKernelGGL(k_selftest_limit, dim3(((1u << 24) + (1u << 26)) / 256), dim3(256), 0, nullptr, d_bad + 3);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(h_bad, d_bad, 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    (void)hipFree(d_bad);
+    return M17GPU_OK;
+}
 
 int m17gpu_set_profiling(m17gpu_ctx *ctx, int on)
 {

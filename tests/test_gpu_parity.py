@@ -147,3 +147,13 @@ def test_stage_demap_and_frontend_match_oracle():
             np.testing.assert_array_equal(disc[c, b].view(np.uint32), d.view(np.uint32))
             assert np.float32(off).view(np.uint32) == offs[c, b].view(np.uint32)
     rx.close()
+
+
+def test_exact_arithmetic_selftest():
+    """The shortened sqrt / reciprocal / int16-scale sequences must equal the literal
+    IEEE / fp64 expressions on every input of their domains (exhaustive, on device)."""
+    _torch()
+    import m17_sdr_amd as m
+    rx = m.Receiver(1, 1)
+    assert rx.selftest() == [0, 0, 0, 0]
+    rx.close()
