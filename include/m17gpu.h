@@ -108,6 +108,11 @@ int m17gpu_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk,
 int m17gpu_sync_frame(m17gpu_ctx *ctx, const float *d_disc, int nblk,
                       m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts,
                       float *d_syms, int32_t *d_nsyms, void *stream);
+/* m17_rx_sync_samples alone (m17_rx_sync.cpp:77-99): timing recovery with the lock
+ * flag of an EXTERNAL framer (what m17_rx_lock() returns, m17_rx_frame.cpp:187),
+ * the same flag for every channel and block of the call.  Framer state untouched. */
+int m17gpu_sync_samples(m17gpu_ctx *ctx, const float *d_disc, int nblk, int lock,
+                        float *d_syms, int32_t *d_nsyms, void *stream);
 /* m17_viterbi_decode (m17_conv.cpp:148-168) on n independent soft-bit vectors:
  * d_soft [n][len] floats -> d_bits [n][len/2] one bit per byte.  len <= 488, even. */
 int m17gpu_viterbi_decode(m17gpu_ctx *ctx, const float *d_soft, uint8_t *d_bits,

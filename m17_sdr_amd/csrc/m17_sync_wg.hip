@@ -121,7 +121,7 @@ __device__ __forceinline__ SyncResult sync_check_wave(const float v[8])
 __global__ __launch_bounds__(WG_T, 4)     // 4 workgroups per CU (1,024 channels on 256 CUs): <= 128 VGPRs
 void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
                      const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
-                     ChanState *__restrict__ st, int C, int nblk, int mode,
+                     ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
                      m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
                      float *__restrict__ syms, int32_t *__restrict__ nsyms,
                      float *__restrict__ fsym, int32_t *__restrict__ work, int32_t *__restrict__ nwork)
@@ -181,8 +181,10 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
         }
 
         // ---- timing recovery: x[i .. i+30] is the delay line at input i; symbols go to h[8+..]
-        const int thresh = flock ? 80 : 10;
-        const int width = flock ? WG_T : 64;
+        // ext_lock >= 0: timing recovery alone, lock flag supplied by the caller's framer (m17_rx_sync.cpp:92-95)
+        const int lockv = (ext_lock >= 0) ? ext_lock : flock;
+        const int thresh = lockv ? 80 : 10;
+        const int width = lockv ? WG_T : 64;
         int p = 0, m_idx = 0;
         while (p < kDiscOut) {
             p = uni(p); m_idx = uni(m_idx); thr = uni(thr); index = uni(index); clk = uni(clk);
@@ -303,7 +305,7 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
         sym_total += n;
 
         // ---- framer (m17_rx_frame.cpp:126-177)
-        int pos = 0;
+        int pos = (ext_lock >= 0) ? n : 0;
         while (pos < n) {
             if (flock) {
                 const int cnt = min(kFrameSyms - fclk, n - pos);

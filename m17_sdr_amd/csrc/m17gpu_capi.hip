@@ -100,11 +100,11 @@ int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc,
 
 int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int nblk, int mode,
                       m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, float *d_syms, int32_t *d_nsyms,
-                      hipStream_t st)
+                      hipStream_t st, int ext_lock = -1)
 {
-    if (ctx->sync_impl == 1)
+    if (ctx->sync_impl == 1 || ext_lock >= 0)
         hipLaunchKernelGGL(k_sync_frame_wg, dim3(ctx->C), dim3(WG_T), 0, st,
-                           disc, offs, ctx->d_state, ctx->C, nblk, mode,
+                           disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
                            ctx->d_fsym, ctx->d_work, ctx->d_nwork);
@@ -319,6 +319,14 @@ int m17gpu_sync_frame(m17gpu_ctx *ctx, const float *d_disc, int nblk, m17gpu_rec
 {
     if (!ctx || !d_disc || nblk <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_sync_frame: bad argument");
     return launch_sync_frame(ctx, d_disc, nullptr, nblk, 0, d_recs, rec_cap, d_counts, d_syms, d_nsyms, S(stream));
+}
+
+int m17gpu_sync_samples(m17gpu_ctx *ctx, const float *d_disc, int nblk, int lock, float *d_syms,
+                        int32_t *d_nsyms, void *stream)
+{
+    if (!ctx || !d_disc || !d_syms || nblk <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_sync_samples: bad argument");
+    return launch_sync_frame(ctx, d_disc, nullptr, nblk, 0, nullptr, 0, nullptr, d_syms, d_nsyms, S(stream),
+                             lock ? 1 : 0);
 }
 
 int m17gpu_viterbi_decode(m17gpu_ctx *ctx, const float *d_soft, uint8_t *d_bits, int len, int n, void *stream)
