@@ -126,6 +126,12 @@ int m17gpu_decode_frames(m17gpu_ctx *ctx, const float *d_sym, const uint8_t *d_t
 /* m_17_golay_decode (m17_golay.cpp:103-116) on n 24-bit words: d_out[i] = data | weight<<12 */
 int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_out, int n, void *stream);
 
+/* Kernel-variant selectors (A/B measurement, and so the parity tests cover every
+ * variant): "sync_impl" 2 = wave per channel (default), 1 = workgroup per channel,
+ * 0 = first version; "fast_windows" 0|1 (multi-block windows of sync_impl 1);
+ * "fe_impl" 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block. */
+int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value);
+
 /* ---------------- measurement hooks ---------------- */
 /* When on, m17gpu_rx_blocks brackets each of its kernels with HIP events on the
  * launch stream (up to 512 calls are kept).  m17gpu_get_kernel_ms waits for the

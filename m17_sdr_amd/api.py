@@ -129,6 +129,9 @@ class Receiver:
         _check(lib().m17gpu_golay_decode(self._ctx, _ptr(words), _ptr(out), n, _stream()), "m17gpu_golay_decode")
         return out
 
+    def set_option(self, name, value):
+        _check(lib().m17gpu_set_option(self._ctx, name.encode(), int(value)), "m17gpu_set_option")
+
     # ---- measurement ---------------------------------------------------------
     def set_profiling(self, on):
         _check(lib().m17gpu_set_profiling(self._ctx, int(bool(on))), "m17gpu_set_profiling")

@@ -25,18 +25,27 @@
 
 namespace m17dev {
 
-constexpr int WG_T = 256;
+constexpr int WG_T = 128;                                // threads per channel (two waves)
+constexpr int NW   = WG_T / 64;
+constexpr int PF_N = kDiscOut * 4 / WG_T;                // staged inputs per thread (12)
+
+constexpr int WIN  = 4;                                   // blocks staged in LDS at a time
+constexpr int XLEN = kTaps - 1 + kDiscOut * WIN + 2;
 
 struct WgShared {
     float mf[kPhases][32];
     float md[kPhases][32];
-    float xa[kTaps - 1 + kDiscOut + 2];    // xa[i] = x[i]   (x[0..29] history, x[30..413] this block)
-    float xb[kTaps - 1 + kDiscOut + 2];    // xb[i] = x[i+1]
+    float xa[XLEN];                        // xa[i] = x[i]   (x[0..29] history, then WIN blocks of 384 inputs)
+    float xb[XLEN];                        // xb[i] = x[i+1]
     float sums[2][WG_T], difs[2][WG_T];
-    float h[8 + 264];                      // m_sync (8) followed by the block's symbols
+    float h[8 + kFrameSyms * WIN + 16];    // m_sync (8) followed by the symbols of the block / window
     float f[kFrameSyms];                   // m_f_sym
-    unsigned long long up[2][4], dn[2][4], hit[4];
+    unsigned long long up[2][NW], dn[2][NW], hit[NW];
+    unsigned long long fup[3 * 4], fdn[3 * 4];             // fast window: ballots of 12 x 64 instants
     float bc_var; int bc_type, bc_votes;
+    float fr_var[WIN]; int fr_type[WIN], fr_votes[WIN];    // fast window: sync class of each frame
+    float last_sum, last_dif; int fast_abort;
+    float poff[WIN];                       // DC offsets of the staged blocks
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
@@ -52,11 +61,13 @@ __device__ __forceinline__ void lds_barrier()
 
 #ifdef M17_STAMPS
 __device__ unsigned long long g_stamps[16];
+#define DBGCNT(i) do { if (t == 0) atomicAdd(&g_stamps[12 + (i)], 1ull); } while (0)
 #define STAMP(i) do { unsigned long long now_; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
     acc_[i] += now_ - last_; last_ = now_; } while (0)
 #else
 #define STAMP(i) do {} while (0)
+#define DBGCNT(i) do {} while (0)
 #endif
 
 // The control state of a channel is wave-uniform by construction; telling the
@@ -69,11 +80,11 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__device__ __forceinline__ int first_set4(const unsigned long long m[4])
+__device__ __forceinline__ int first_set4(const unsigned long long m[NW])
 {
     int k = -1;
 #pragma unroll
-    for (int w = 3; w >= 0; --w)
+    for (int w = NW - 1; w >= 0; --w)
         if (m[w]) k = 64 * w + __ffsll((long long)m[w]) - 1;
     return k;
 }
@@ -118,13 +129,48 @@ __device__ __forceinline__ SyncResult sync_check_wave(const float v[8])
     return r;
 }
 
-__global__ __launch_bounds__(WG_T, 4)     // 4 workgroups per CU (1,024 channels on 256 CUs): <= 128 VGPRs
+// One symbol instant: the matched (s) and derivative (d) 31-tap dot products over the
+// delay line xs[0..30], strictly in the reference's order (rx_sync_filter,
+// m17_rx_sync.cpp:25-31: bare first product, then += in ascending tap order, separate
+// multiply and add).  31 taps in four groups of 8 (last: 7); the next group's LDS reads
+// (taps are wave-uniform broadcasts) are issued before the current group's chain.
+__device__ __forceinline__ void fir_instant(const float *xs, const float4 *mf4, const float4 *md4, float &s, float &d)
+{
+    const float2 *xp = reinterpret_cast<const float2 *>(xs);
+    float4 ma = mf4[0], mb = mf4[1], da = md4[0], db = md4[1];
+    float2 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 nma = ma, nmb = mb, nda = da, ndb = db;
+        float2 y0 = x0, y1 = x1, y2 = x2, y3 = x3;
+        if (g < 3) {
+            nma = mf4[2 * g + 2]; nmb = mf4[2 * g + 3]; nda = md4[2 * g + 2]; ndb = md4[2 * g + 3];
+            y0 = xp[4 * g + 4]; y1 = xp[4 * g + 5]; y2 = xp[4 * g + 6];
+            if (g < 2) y3 = xp[4 * g + 7];
+            else { y3.x = xs[30]; y3.y = 0.0f; }
+        }
+        if (g == 0) { s = x0.x * ma.x; d = x0.x * da.x; }    // bare first product
+        else        { s += x0.x * ma.x; d += x0.x * da.x; }
+        s += x0.y * ma.y; d += x0.y * da.y;
+        s += x1.x * ma.z; d += x1.x * da.z;
+        s += x1.y * ma.w; d += x1.y * da.w;
+        s += x2.x * mb.x; d += x2.x * db.x;
+        s += x2.y * mb.y; d += x2.y * db.y;
+        s += x3.x * mb.z; d += x3.x * db.z;
+        if (g < 3) { s += x3.y * mb.w; d += x3.y * db.w; }   // tap 31 does not exist
+        ma = nma; mb = nmb; da = nda; db = ndb;
+        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+    }
+}
+
+__global__ __launch_bounds__(WG_T, 2)     // 1,024 channels x 2 waves = 2 waves per SIMD: <= 256 VGPRs, no spills
 void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
                      const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
                      ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
                      m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
                      float *__restrict__ syms, int32_t *__restrict__ nsyms,
-                     float *__restrict__ fsym, int32_t *__restrict__ work, int32_t *__restrict__ nwork)
+                     float *__restrict__ fsym, int32_t *__restrict__ work, int32_t *__restrict__ nwork,
+                     int allow_fast)
 {
     __shared__ __attribute__((aligned(16))) WgShared sh;
     const int t = (int)threadIdx.x, w = t >> 6, lane = t & 63;
@@ -147,39 +193,199 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
         if (t >= 1) sh.xb[t - 1] = v;
     }
     if (t < 8) sh.h[t] = cs.sync[t];
-    if (t < kFrameSyms) sh.f[t] = cs.fsym[t];
+    for (int q = t; q < kFrameSyms; q += WG_T) sh.f[q] = cs.fsym[q];
+    if (t == 0) sh.fast_abort = 0;
     int nrec = 0, sym_total = 0, par = 0;
     const size_t sym_base = (size_t)chan * M17_SYM_STRIDE(nblk);
     const float *dsrc = disc + (size_t)chan * nblk * kDiscOut;
     const float *osrc = offs ? offs + (size_t)chan * nblk : nullptr;
 
-    // block 0 input (DC removed, m17_dsp.cpp:217-219)
-    {
-        const float off = osrc ? osrc[0] : 0.0f;
-        float v0 = dsrc[t];
-        float v1 = (t + WG_T < kDiscOut) ? dsrc[t + WG_T] : 0.0f;
-        if (osrc) { v0 = v0 - off; v1 = v1 - off; }
-        sh.xa[kTaps - 1 + t] = v0; sh.xb[kTaps - 2 + t] = v0;
-        if (t + WG_T < kDiscOut) { sh.xa[kTaps - 1 + t + WG_T] = v1; sh.xb[kTaps - 2 + t + WG_T] = v1; }
-    }
+    // ---- staging of up to WIN blocks: 6 inputs per thread, prefetched one window ahead.
+    // Element r of thread t is input (t + 256 r) of the window: block (t+256r)/384.
+    float pf[PF_N], po1 = 0.0f;                 // po1: DC offset of block (t & 3) of the prefetched window
+// (to_ is an opaque copy of t: keeps the compiler from hoisting ~30 loop-invariant
+//  addresses out of the block loop and spilling them)
+#define SF_PREFETCH(WB) { int to_ = t; asm volatile("" : "+v"(to_));                 \
+    _Pragma("unroll") for (int r = 0; r < PF_N; ++r) {                                  \
+        const int e_ = to_ + WG_T * r, jj_ = e_ / kDiscOut;                          \
+        pf[r] = (((WB) + jj_) < nblk) ? dsrc[(size_t)(WB) * kDiscOut + e_] : 0.0f;   \
+    }                                                                                \
+    po1 = (osrc && t < WIN && ((WB) + t) < nblk) ? osrc[(WB) + t] : 0.0f; }
+#define SF_POFF()   if (t < WIN) sh.poff[t] = po1;       /* before the barrier that precedes SF_COMMIT */
+#define SF_COMMIT() { int to_ = t; asm volatile("" : "+v"(to_)); /* out[i] - offset (m17_dsp.cpp:217-219) */ \
+    _Pragma("unroll") for (int r = 0; r < PF_N; ++r) {                                  \
+        const int e_ = to_ + WG_T * r;                                               \
+        const float v_ = osrc ? (pf[r] - sh.poff[e_ / kDiscOut]) : pf[r];            \
+        sh.xa[kTaps - 1 + e_] = v_;                                                  \
+        sh.xb[kTaps - 2 + e_] = v_;                                                  \
+    } }
+    SF_PREFETCH(0)
+    SF_POFF()
+    lds_barrier();
+    SF_COMMIT()
+    int wb = 0, staged = min(WIN, nblk);
+    if (staged < nblk) { SF_PREFETCH(WIN) }
     lds_barrier();
 
 #ifdef M17_STAMPS
     unsigned long long acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, last_ = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    for (int b = 0; b < nblk; ++b) {
+    int b = 0;
+    while (b < nblk) {
         STAMP(0);
-        // prefetch the next block's input; it is committed to LDS at the end of this block
-        // (the DC subtraction is deferred to the commit so that nothing waits on these loads here)
-        float n0 = 0.0f, n1 = 0.0f, noff = 0.0f;
-        if (b + 1 < nblk) {
-            const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
-            noff = osrc ? osrc[b + 1] : 0.0f;
-            n0 = nx[t];
-            n1 = (t + WG_T < kDiscOut) ? nx[t + WG_T] : 0.0f;
+        if (b == wb + staged) {
+            // restage: the last 30 inputs become the delay line, the prefetched window moves in
+            float keep_x = 0.0f;
+            if (t < kTaps - 1) keep_x = sh.xa[kDiscOut * staged + t];
+            SF_POFF()
+            lds_barrier();
+            if (t < kTaps - 1) {
+                sh.xa[t] = keep_x;
+                if (t >= 1) sh.xb[t - 1] = keep_x;
+            }
+            SF_COMMIT()
+            wb = b; staged = min(WIN, nblk - b);
+            if (wb + WIN < nblk) { SF_PREFETCH(wb + WIN) }
+            lds_barrier();
+        }
+        const int j = b - wb;
+        const int xoff = kDiscOut * j;
+        const int brem = staged - j;
+
+        // =========================== fast window ===========================
+        if (allow_fast && ext_lock < 0 && flock && brem >= 2 && fclk >= 8) {
+            const int NT = kFrameSyms * brem;            // filter instants in the window
+            int thr0 = thr, p0 = 0;
+            bool go = true;
+            if (clk == 1) {                              // carried vote tick, tentatively
+                const float d0 = (sum < 0.0f) ? -dif : dif;
+                if (d0 > 0.0f) thr0++;
+                if (d0 < 0.0f) thr0--;
+                p0 = 1;
+                go = !(thr0 > 80 || thr0 < -80);
+            }
+            DBGCNT(0);
+            if (go) {
+                const float4 *fmf4 = reinterpret_cast<const float4 *>(sh.mf[index]);
+                const float4 *fmd4 = reinterpret_cast<const float4 *>(sh.md[index]);
+#pragma unroll 3          // three instants in flight per thread: six independent add chains hide the VALU latency
+                for (int r = 0; r < 768 / WG_T; ++r) {
+                    const int k = t + WG_T * r;
+                    if (WG_T * r < NT) {                                  // uniform
+                        const bool have = k < NT;
+                        const int ik = p0 + 2 * (have ? k : 0);
+                        const int a = xoff + ik;
+                        const float *xs = (a & 1) ? (sh.xb + (a - 1)) : (sh.xa + a);
+                        float s, d;
+                        fir_instant(xs, fmf4, fmd4, s, d);
+                        if (have) sh.h[8 + k] = s;
+                        if (k == NT - 1) { sh.last_sum = s; sh.last_dif = d; }
+                        const bool vote_ok = have && (p0 + 2 * k + 1 < kDiscOut * brem);
+                        const float dd = (s < 0.0f) ? -d : d;
+                        const unsigned long long upm = __ballot(vote_ok && dd > 0.0f);
+                        const unsigned long long dnm = __ballot(vote_ok && dd < 0.0f);
+                        if (lane == 0) { sh.fup[r * NW + w] = upm; sh.fdn[r * NW + w] = dnm; }
+                    } else if (lane == 0) { sh.fup[r * NW + w] = 0; sh.fdn[r * NW + w] = 0; }
+                }
+                STAMP(8);
+                lds_barrier();
+                // scan: segment g = r*NW + w' holds instants 64 g .. 64 g + 63; wave w checks 12/NW of the 12
+                int tot_all = 0;
+                {
+                    const unsigned long long incl = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                    int running = thr0;
+                    bool crossed = false;
+#pragma unroll
+                    for (int g = 0; g < 12; ++g) {
+                        const unsigned long long Ug = uni64(sh.fup[g]), Dg = uni64(sh.fdn[g]);
+                        if (g >= (12 / NW) * w && g < (12 / NW) * (w + 1)) {
+                            const int tk = running + __popcll(Ug & incl) - __popcll(Dg & incl);
+                            crossed = crossed || (tk > 80 || tk < -80);
+                        }
+                        running += (int)__popcll(Ug) - (int)__popcll(Dg);
+                    }
+                    tot_all = running;
+                    if (__ballot(crossed) != 0ull && lane == 0) sh.fast_abort = 1;
+                }
+                STAMP(9);
+                // frames: wave w classifies frames w, w+NW, ... by their leading sync words
+                for (int fq = w; fq < brem; fq += NW) {
+                    float v[8];
+                    const int first = (fq == 0) ? 0 : (8 + (kFrameSyms - fclk) + kFrameSyms * (fq - 1));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (fq == 0) ? sh.f[i] : sh.h[first + i];
+                    const SyncResult r0 = sync_check_wave(v);
+                    const bool clean = r0.type >= 1 && r0.type <= 4 && sync_accept(r0, true);
+                    if (lane == 0) {
+                        sh.fr_type[fq] = r0.type; sh.fr_votes[fq] = r0.votes; sh.fr_var[fq] = r0.variance;
+                        if (!clean) sh.fast_abort = 1;
+                    }
+                }
+                lds_barrier();
+                STAMP(10);
+                const int aborted = uni(sh.fast_abort);
+                if (!aborted) {
+                    DBGCNT(1);
+                    // ---- commit the window
+                    thr = tot_all; clk = (p0 == 0) ? 0 : 1;
+                    sum = unif(sh.last_sum); dif = unif(sh.last_dif);
+                    ferr = 0;
+#pragma unroll
+                    for (int r = 0; r < 768 / WG_T; ++r) {
+                        const int k = t + WG_T * r;
+                        if (syms && k < NT) syms[sym_base + sym_total + k] = sh.h[8 + k];
+                    }
+                    if (nsyms && t < brem) nsyms[(size_t)chan * nblk + b + t] = kFrameSyms;
+                    const uint32_t fl = M17_F_SYNC_OK | ((mode == 1) ? M17_F_PARSED : 0u);
+                    if (w == 0) {
+                        for (int fq = 0; fq < brem; ++fq) {
+                            const int cpos = (kFrameSyms - 1 - fclk) + kFrameSyms * fq;    // completing symbol
+                            emit_record(crecs, rec_cap, nrec + fq,
+                                        (uint32_t)uni(sh.fr_type[fq]) | ((uint32_t)uni(sh.fr_votes[fq]) << 8), fl,
+                                        unif(sh.fr_var[fq]), block_count + (uint32_t)(cpos / kFrameSyms),
+                                        (uint32_t)(cpos % kFrameSyms));
+                        }
+                    }
+                    if (mode == 1) {
+                        int wbase = 0;
+                        if (t == 0) {
+                            int nq = 0;
+                            for (int q = 0; q < brem; ++q) {
+                                const int ty = sh.fr_type[q];
+                                if (nrec + q < rec_cap && ty >= 1 && ty <= 3) nq++;
+                            }
+                            wbase = nq ? atomicAdd(nwork, nq) : 0;
+                            int at = 0;
+                            for (int q = 0; q < brem; ++q) {
+                                const int ty = sh.fr_type[q];
+                                if (nrec + q < rec_cap && ty >= 1 && ty <= 3) work[wbase + at++] = chan * rec_cap + nrec + q;
+                            }
+                        }
+                        for (int q = 0; q < brem; ++q) {
+                            const int ty = uni(sh.fr_type[q]);
+                            if (nrec + q < rec_cap && ty >= 1 && ty <= 3) {
+                                float *fd = fsym + ((size_t)chan * rec_cap + nrec + q) * kFrameSyms;
+                                for (int u = t; u < kFrameSyms; u += WG_T)
+                                    fd[u] = (q == 0) ? ((u < fclk) ? sh.f[u] : sh.h[8 + u - fclk])
+                                                     : sh.h[8 + (kFrameSyms - fclk) + kFrameSyms * (q - 1) + u];
+                            }
+                        }
+                    }
+                    lds_barrier();                              // frame 0 has read f
+                    for (int u = t; u < fclk; u += WG_T) sh.f[u] = sh.h[8 + (kFrameSyms - fclk) + kFrameSyms * (brem - 1) + u];
+                    nrec += brem; block_count += (uint32_t)brem; sym_total += NT; b += brem;
+                    lds_barrier();
+                    STAMP(11);
+                    continue;
+                }
+                if (t == 0) sh.fast_abort = 0;
+                lds_barrier();
+            }
         }
 
+        DBGCNT(2);
+        // =========================== exact per-block path ===========================
         // ---- timing recovery: x[i .. i+30] is the delay line at input i; symbols go to h[8+..]
         // ext_lock >= 0: timing recovery alone, lock flag supplied by the caller's framer (m17_rx_sync.cpp:92-95)
         const int lockv = (ext_lock >= 0) ? ext_lock : flock;
@@ -211,37 +417,10 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
             const bool have = t < nf;
             float s = 0.0f, d = 0.0f;
             if (w * 64 < nf) {                                  // wave-uniform: this wave has instants to evaluate
-                const int a = have ? ik : p;
+                const int a = xoff + (have ? ik : p);
                 const float *xs = (a & 1) ? (sh.xb + (a - 1)) : (sh.xa + a);
-                const float2 *xp = reinterpret_cast<const float2 *>(xs);
-                const float4 *mf4 = reinterpret_cast<const float4 *>(sh.mf[index]);   // broadcast reads
-                const float4 *md4 = reinterpret_cast<const float4 *>(sh.md[index]);
-                // 31 taps in four groups of 8 (last: 7); the next group's LDS reads are issued
-                // before the current group's strictly ordered mul/add chain (rx_sync_filter :25-31)
-                float4 ma = mf4[0], mb = mf4[1], da = md4[0], db = md4[1];
-                float2 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4 nma = ma, nmb = mb, nda = da, ndb = db;
-                    float2 y0 = x0, y1 = x1, y2 = x2, y3 = x3;
-                    if (g < 3) {
-                        nma = mf4[2 * g + 2]; nmb = mf4[2 * g + 3]; nda = md4[2 * g + 2]; ndb = md4[2 * g + 3];
-                        y0 = xp[4 * g + 4]; y1 = xp[4 * g + 5]; y2 = xp[4 * g + 6];
-                        if (g < 2) y3 = xp[4 * g + 7];
-                        else { y3.x = xs[30]; y3.y = 0.0f; }
-                    }
-                    if (g == 0) { s = x0.x * ma.x; d = x0.x * da.x; }    // bare first product
-                    else        { s += x0.x * ma.x; d += x0.x * da.x; }
-                    s += x0.y * ma.y; d += x0.y * da.y;
-                    s += x1.x * ma.z; d += x1.x * da.z;
-                    s += x1.y * ma.w; d += x1.y * da.w;
-                    s += x2.x * mb.x; d += x2.x * db.x;
-                    s += x2.y * mb.y; d += x2.y * db.y;
-                    s += x3.x * mb.z; d += x3.x * db.z;
-                    if (g < 3) { s += x3.y * mb.w; d += x3.y * db.w; }   // tap 31 does not exist
-                    ma = nma; mb = nmb; da = nda; db = ndb;
-                    x0 = y0; x1 = y1; x2 = y2; x3 = y3;
-                }
+                fir_instant(xs, reinterpret_cast<const float4 *>(sh.mf[index]),
+                            reinterpret_cast<const float4 *>(sh.md[index]), s, d);
             }
             STAMP(1);
             sh.sums[par][t] = s; sh.difs[par][t] = d;
@@ -256,7 +435,7 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
             const unsigned long long incl = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
             int running = thr, kstar = -1, ts = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NW; ++q) {
                 const unsigned long long Uq = uni64(sh.up[par][q]), Dq = uni64(sh.dn[par][q]);
                 if (q * 64 < nf) {
                     const int tk = running + __popcll(Uq & incl) - __popcll(Dq & incl);
@@ -300,7 +479,7 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
         STAMP(4);
 
         // symbols out (optional)
-        if (syms && t < n) syms[sym_base + sym_total + t] = sh.h[8 + t];
+        if (syms) for (int q = t; q < n; q += WG_T) syms[sym_base + sym_total + q] = sh.h[8 + q];
         if (nsyms && t == 0) nsyms[(size_t)chan * nblk + b] = n;
         sym_total += n;
 
@@ -309,7 +488,7 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
         while (pos < n) {
             if (flock) {
                 const int cnt = min(kFrameSyms - fclk, n - pos);
-                if (t < cnt) sh.f[fclk + t] = sh.h[8 + pos + t];
+                for (int q = t; q < cnt; q += WG_T) sh.f[fclk + q] = sh.h[8 + pos + q];
                 fclk += cnt; pos += cnt;
                 if (fclk == kFrameSyms) {
                     fclk = 0;
@@ -340,7 +519,7 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
                         emit_record(crecs, rec_cap, nrec, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
                     if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
                         float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kFrameSyms;
-                        if (t < kFrameSyms) fd[t] = sh.f[t];
+                        for (int q = t; q < kFrameSyms; q += WG_T) fd[q] = sh.f[q];
                         if (t == 0) work[atomicAdd(nwork, 1)] = chan * rec_cap + nrec;
                     }
                     nrec++;
@@ -353,9 +532,9 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
                 }
             } else {
                 // hunt: candidate j = pos+t, window = m_sync after shifting symbol j in
-                const int j = pos + t;
-                const bool cand = j < n;
-                const int jj = cand ? j : pos;
+                const int jc = pos + t;
+                const bool cand = jc < n;
+                const int jj = cand ? jc : pos;
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = sh.h[jj + 1 + i];
@@ -363,9 +542,9 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
                 const unsigned long long hm = __ballot(cand && sync_accept(r, false));
                 if (lane == 0) sh.hit[w] = hm;
                 lds_barrier();
-                unsigned long long H[4];
+                unsigned long long H[NW];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) H[q] = uni64(sh.hit[q]);
+                for (int q = 0; q < NW; ++q) H[q] = uni64(sh.hit[q]);
                 const int l = first_set4(H);
                 if (l >= 0) {
                     const int js = pos + l;
@@ -388,25 +567,15 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
             }
         }
         STAMP(5);
-        // m_sync for the next block while hunting: last 8 entries of h;
-        // delay line for the next block: last 30 inputs; then commit the prefetched input
+        // m_sync for the next block while hunting: last 8 entries of h
         {
-            float keep_h = 0.0f, keep_x = 0.0f;
+            float keep_h = 0.0f;
             if (t < 8) keep_h = sh.h[n + t];
-            if (t < kTaps - 1) keep_x = sh.xa[kDiscOut + t];
             lds_barrier();
             if (!flock && t < 8) { sh.h[t] = keep_h; cs.sync[t] = keep_h; }
-            if (t < kTaps - 1) {
-                sh.xa[t] = keep_x;
-                if (t >= 1) sh.xb[t - 1] = keep_x;
-            }
-            if (b + 1 < nblk) {
-                if (osrc) { n0 = n0 - noff; n1 = n1 - noff; }     // out[i] - offset (m17_dsp.cpp:217-219)
-                sh.xa[kTaps - 1 + t] = n0; sh.xb[kTaps - 2 + t] = n0;
-                if (t + WG_T < kDiscOut) { sh.xa[kTaps - 1 + t + WG_T] = n1; sh.xb[kTaps - 2 + t + WG_T] = n1; }
-            }
         }
         block_count++;
+        b++;
         lds_barrier();
         STAMP(6);
     }
@@ -414,15 +583,15 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
     if (chan == 0 && t == 0) for (int i = 0; i < 12; ++i) g_stamps[i] = acc_[i];
 #endif
 
-    // ---- store state
+    // ---- store state: the last 30 inputs of the staged buffer are the delay line
     if (t == 0) {
         cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum; cs.dif = dif;
         cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count;
         cs.buff[0] = 0.0f;
         if (counts) counts[chan] = nrec;
     }
-    if (t < kTaps - 1) cs.buff[t + 1] = sh.xa[t];
-    if (t < kFrameSyms) cs.fsym[t] = sh.f[t];
+    if (t < kTaps - 1) cs.buff[t + 1] = sh.xa[kDiscOut * staged + t];
+    for (int q = t; q < kFrameSyms; q += WG_T) cs.fsym[q] = sh.f[q];
 }
 
 } // namespace m17dev

@@ -2,6 +2,7 @@
 // No CPU fallback: every compute entry point needs a HIP device.
 #include "m17_kernels.hip"
 #include "m17_sync_wg.hip"
+#include "m17_sync_wave.hip"
 #include "m17_host.h"
 #include "../../include/m17gpu.h"
 #include <string>
@@ -26,7 +27,8 @@ struct m17gpu_ctx {
     uint16_t *d_genc = nullptr, *d_gerr = nullptr;
     bool profiling = false;
     int fe_impl = 0;                         // 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block
-    int sync_impl = 1;                       // 1 = workgroup per channel (default), 0 = wave per channel
+    int sync_impl = 2;                       // 2 = wave per channel (default), 1 = workgroup per channel, 0 = first version
+    int allow_fast = 0;                      // multi-block fast windows in k_sync_frame_wg                       // 1 = workgroup per channel (default), 0 = wave per channel
     std::vector<hipEvent_t> ev_pool;         // 5 events per profiled call
     std::vector<int> ev_mode;                // mode of each profiled call
 };
@@ -102,12 +104,18 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
                       m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, float *d_syms, int32_t *d_nsyms,
                       hipStream_t st, int ext_lock = -1)
 {
-    if (ctx->sync_impl == 1 || ext_lock >= 0)
-        hipLaunchKernelGGL(k_sync_frame_wg, dim3(ctx->C), dim3(WG_T), 0, st,
+    if (ctx->sync_impl == 2)
+        hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(ctx->C, SW_WAVES)), dim3(64 * SW_WAVES), 0, st,
                            disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
                            ctx->d_fsym, ctx->d_work, ctx->d_nwork);
+    else if (ctx->sync_impl == 1 || ext_lock >= 0)
+        hipLaunchKernelGGL(k_sync_frame_wg, dim3(ctx->C), dim3(WG_T), 0, st,
+                           disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
+                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
+                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
+                           ctx->d_fsym, ctx->d_work, ctx->d_nwork, ctx->allow_fast);
     else
         hipLaunchKernelGGL(k_sync_frame, dim3(cdiv(ctx->C, SF_WAVES)), dim3(64 * SF_WAVES), 0, st,
                            disc, offs, ctx->d_state, ctx->C, nblk, mode,
@@ -143,8 +151,9 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     if (!ctx) return fail(M17GPU_ERR_NOMEM, "m17gpu_create: out of host memory");
     ctx->device = device; ctx->C = n_channels; ctx->max_blocks = max_blocks;
     ctx->rec_cap_max = 2 * max_blocks + 2;
+    if (const char *e = std::getenv("M17GPU_FAST_WINDOWS")) ctx->allow_fast = std::atoi(e);
     if (const char *e = std::getenv("M17GPU_FE_IMPL")) ctx->fe_impl = std::atoi(e);
-    if (const char *e = std::getenv("M17GPU_SYNC_IMPL")) ctx->sync_impl = (std::strcmp(e, "w64") == 0) ? 0 : 1;
+    if (const char *e = std::getenv("M17GPU_SYNC_IMPL")) ctx->sync_impl = std::atoi(e);
     const size_t cb = (size_t)n_channels * max_blocks;
     int rc = upload_tables(ctx);
     if (rc != M17GPU_OK) { m17gpu_destroy(ctx); return rc; }
@@ -266,6 +275,18 @@ int m17gpu_selftest(m17gpu_ctx *ctx, unsigned *h_bad)
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(h_bad, d_bad, 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
     (void)hipFree(d_bad);
+    return M17GPU_OK;
+}
+
+// Implementation selectors, for A/B measurements and so that every kernel variant stays
+// under the parity tests: "sync_impl" 0|1|2, "fast_windows" 0|1, "fe_impl" 0|1|2.
+int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
+{
+    if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
+    if (!std::strcmp(name, "sync_impl")) ctx->sync_impl = value;
+    else if (!std::strcmp(name, "fast_windows")) ctx->allow_fast = value;
+    else if (!std::strcmp(name, "fe_impl")) ctx->fe_impl = value;
+    else return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: unknown option ") + name);
     return M17GPU_OK;
 }
 

@@ -12,7 +12,7 @@ for _ in range(3): rx.rx_blocks(iq, 0, out)
 torch.cuda.synchronize()
 st = (C.c_ulonglong*16)()
 m.lib().m17gpu_debug_stamps(st)
-names = ["blk start", "FIR(+vote tick)", "ballot+barrier", "scan+decide", "post-loop barrier", "syms+framer", "end-of-block commit"]
+names = ["block top (prefetch issue)", "FIR pass (+vote tick)", "scan+decide", "fence", "syms out", "framer", "end-of-block commit"]
 tot = sum(st[:7])
 for i, nme in enumerate(names): print(f"{nme:32s} {st[i]/nblk:9.0f} ticks/block  {100*st[i]/tot:5.1f}%")
 print("total ticks/block", tot/nblk)

@@ -15,12 +15,14 @@ def _torch():
     return torch
 
 
-def _rx_compare(C, nblk, mode, ebn0, nsf=8, packet_mode=0, calls=1, seed=0x4D313700):
+def _rx_compare(C, nblk, mode, ebn0, nsf=8, packet_mode=0, calls=1, seed=0x4D313700, options=None):
     torch = _torch()
     import m17_sdr_amd as m
     sig = m.generate_batch(C, nblk * calls, n_stream_frames=nsf, ebn0_db=ebn0, packet_mode=packet_mode,
                            base_seed=seed)
     rx = m.Receiver(C, nblk)
+    for k, v in (options or {}).items():
+        rx.set_option(k, v)
     och = oracle.Channels(C)
     total_delivered = 0
     for k in range(calls):
@@ -157,3 +159,12 @@ def test_exact_arithmetic_selftest():
     rx = m.Receiver(1, 1)
     assert rx.selftest() == [0, 0, 0, 0]
     rx.close()
+
+
+@pytest.mark.parametrize("options", [
+    {"sync_impl": 0}, {"sync_impl": 1, "fast_windows": 0}, {"sync_impl": 1, "fast_windows": 1},
+    {"sync_impl": 2}, {"fe_impl": 1}, {"fe_impl": 2}])
+def test_every_kernel_variant_is_bit_exact(options):
+    _rx_compare(C=40, nblk=22, mode=1, ebn0=200.0, nsf=12, options=options)
+    _rx_compare(C=40, nblk=9, mode=1, ebn0=9.0, nsf=5, calls=3, options=options)
+    _rx_compare(C=9, nblk=1, mode=0, ebn0=15.0, calls=12, options=options)
