@@ -1,83 +1,77 @@
-// m17_sync_wave.hip -- k_sync_frame_wave: timing recovery + sync correlator + framer
-// with ONE WAVE per channel and no workgroup barrier in the block loop.
+// m17_sync_ch.hip -- k_sync_frame_ch: timing recovery + sync correlator + framer, one
+// 192-thread workgroup per channel with ONE controlling wave.
 //
-// Reference: m17_rx_sync_samples (m17_rx_sync.cpp:77-99) and m17_rx_sym
-// (m17_rx_frame.cpp:126-177).  Same speculation as k_sync_frame_wg -- all symbol
-// instants of a 1920-sample block are evaluated under the current polyphase branch
-// and the vote counter is a popcount prefix over ballots -- but each lane takes
-// three instants (k, k+64, k+128: six independent add chains in flight), the
-// ballots never leave the scalar registers, and the wave owns its channel's LDS
-// arrays outright, so the only synchronisation is the in-order LDS pipeline of one
-// wave.  Measured at 1,024 channels (1 wave per SIMD) this beats the 128/256-thread
-// workgroup variants, whose barriers and duplicated control dominated.
+// Measured on MI355X: a lone wave retires about one instruction per 8 cycles on this
+// control-heavy code, so (a) a single wave per channel spends most of its time in the
+// 192-instant FIR pass, and (b) a workgroup whose waves all execute the control code
+// just multiplies the instruction count.  Here wave 0 runs the channel exactly like
+// k_sync_frame_wave (state, vote scan, framer, stores); waves 1 and 2 do nothing but
+// evaluate instants 64..191 of each full-width pass and sleep at an LDS-only
+// s_barrier otherwise.  While hunting (64-instant passes) the helpers are never woken.
 //
-// LDS per workgroup of 4 waves: one shared copy of both tap tables (10 KB) and,
-// per wave, the block's input with its 30-sample delay line twice (second copy
-// shifted by one float: every (x[a], x[a+1]) pair is an aligned ds_read_b64), the
-// symbol buffer and m_f_sym.
+// Reference: m17_rx_sync_samples (m17_rx_sync.cpp:77-99), m17_rx_sym (m17_rx_frame.cpp:126-177).
 #pragma clang fp contract(off)
 
 namespace m17dev {
 
-constexpr int SW_WAVES = 4;
+constexpr int CH_WAVES = 3;
 
-struct SwWave {
-    float xa[kTaps - 1 + kDiscOut + 2];
-    float xb[kTaps - 1 + kDiscOut + 2];
-    float h[8 + 208];                      // m_sync (8) followed by the block's symbols
-    float f[kFrameSyms];                   // m_f_sym
-};
-struct SwShared {
+struct ChShared {
     float mf[kPhases][32];
     float md[kPhases][32];
-    SwWave wv[SW_WAVES];
+    SwWave wv;
+    float sums[64 * CH_WAVES], difs[64 * CH_WAVES];
+    unsigned long long up[CH_WAVES], dn[CH_WAVES];
+    int go, p, index, nf;
 };
 
-__device__ __forceinline__ void wave_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-}
-
-// candidate pre-filter of the sync hunt: m17_unlocked_sync_check needs votes == 0 for
-// the winning template, i.e. no symbol of the window may have the sign OPPOSITE to
-// that template (zeros and NaNs never vote, m17_rx_frame.cpp:77-80).  A window that
-// is incompatible with all four acceptable templates (types 1..4) cannot be accepted.
-__device__ __forceinline__ bool hunt_compatible(const float v[8])
-{
-    unsigned pos = 0, neg = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        pos |= (v[i] > 0.0f) ? (1u << i) : 0u;
-        neg |= (v[i] < 0.0f) ? (1u << i) : 0u;
-    }
-    constexpr unsigned tn[4] = {0xB0, 0x4F, 0xF2, 0x0D};     // bit i set: template symbol i is -1
-    bool ok = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ok = ok || (((pos & tn[k]) == 0u) && ((neg & (~tn[k] & 0xFFu)) == 0u));
-    return ok;
-}
-
-__global__ __launch_bounds__(64 * SW_WAVES)
-void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
+__global__ __launch_bounds__(64 * CH_WAVES)
+void k_sync_frame_ch(const float *__restrict__ disc,     // [C][nblk][384]
                        const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
                        ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
                        m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
                        float *__restrict__ syms, int32_t *__restrict__ nsyms,
                        float *__restrict__ fsym, int32_t *__restrict__ work, int32_t *__restrict__ nwork)
 {
-    __shared__ __attribute__((aligned(16))) SwShared sh;
+    __shared__ __attribute__((aligned(16))) ChShared sh;
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    for (int q = (int)threadIdx.x; q < kPhases * 32; q += 64 * SW_WAVES) {
+    for (int q = (int)threadIdx.x; q < kPhases * 32; q += 64 * CH_WAVES) {
         // taps interleaved as (matched, derivative) pairs: row idx = 64 floats starting at &sh.mf[0][0] + 64 idx
         (&sh.mf[0][0])[2 * q] = (&c_tab.mf[0][0])[q];
         (&sh.mf[0][0])[2 * q + 1] = (&c_tab.md[0][0])[q];
     }
-    __syncthreads();                                    // the only workgroup barrier
-    const int chan = (int)blockIdx.x * SW_WAVES + wave;
-    if (chan >= C) return;
-    SwWave &my = sh.wv[wave];
+    if (threadIdx.x == 0) sh.go = 1;
+    __syncthreads();
+    const int chan = (int)blockIdx.x;
+    SwWave &my = sh.wv;
+
+    if (wave != 0) {
+        // ---- FIR helper: evaluate instants 64*wave .. 64*wave+63 of every full-width pass
+        for (;;) {
+            lds_barrier();                                           // A: command posted
+            if (!uni(sh.go)) break;
+            const int hp = uni(sh.p), hindex = uni(sh.index), hnf = uni(sh.nf);
+            const int k = 64 * wave + lane;
+            unsigned long long um = 0, dm = 0;
+            if (64 * wave < hnf) {
+                const bool have = k < hnf;
+                const int a = hp + 2 * (have ? k : 0);
+                const float *xs = (a & 1) ? (my.xb + (a - 1)) : (my.xa + a);
+                float s, d;
+                fir_instant(xs, reinterpret_cast<const float4 *>(&sh.mf[0][0] + 64 * hindex),
+                            reinterpret_cast<const float4 *>(sh.md[hindex]), s, d);
+                sh.sums[k] = s; sh.difs[k] = d;
+                const bool vote_ok = have && (hp + 2 * k + 1 < kDiscOut);
+                const float dd = (s < 0.0f) ? -d : d;
+                um = __ballot(vote_ok && dd > 0.0f);
+                dm = __ballot(vote_ok && dd < 0.0f);
+            }
+            if (lane == 0) { sh.up[wave] = um; sh.dn[wave] = dm; }
+            lds_barrier();                                           // B: results visible
+        }
+        return;
+    }
+    // ---- wave 0: the channel's controller (everything below), plus instants 0..63 of each pass
     ChanState &cs = st[chan];
     m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
 
@@ -155,20 +149,28 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
             const int nf = min(width, (kDiscOut - p + 1) >> 1);
             const float4 *mf4 = reinterpret_cast<const float4 *>(&sh.mf[0][0] + 64 * index);
             const float4 *md4 = reinterpret_cast<const float4 *>(sh.md[index]);
-            float sv[3] = {0.0f, 0.0f, 0.0f}, dv[3] = {0.0f, 0.0f, 0.0f};
             unsigned long long U[3] = {0, 0, 0}, D[3] = {0, 0, 0};
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                if (64 * r < nf) {                                   // uniform
-                    const int k = lane + 64 * r;
-                    const bool have = k < nf;
-                    const int a = p + 2 * (have ? k : 0);
-                    const float *xs = (a & 1) ? (my.xb + (a - 1)) : (my.xa + a);
-                    fir_instant(xs, mf4, md4, sv[r], dv[r]);
-                    const bool vote_ok = have && (p + 2 * k + 1 < kDiscOut);
-                    const float dd = (sv[r] < 0.0f) ? -dv[r] : dv[r];
-                    U[r] = __ballot(vote_ok && dd > 0.0f);
-                    D[r] = __ballot(vote_ok && dd < 0.0f);
+            float s0, d0;
+            {
+                if (nf > 64) {                                   // full-width pass: wake the helpers
+                    if (lane == 0) { sh.p = p; sh.index = index; sh.nf = nf; }
+                    lds_barrier();                               // A
+                }
+                const bool have = lane < nf;
+                const int a = p + 2 * (have ? lane : 0);
+                const float *xs = (a & 1) ? (my.xb + (a - 1)) : (my.xa + a);
+                fir_instant(xs, mf4, md4, s0, d0);
+                sh.sums[lane] = s0; sh.difs[lane] = d0;
+                const bool vote_ok = have && (p + 2 * lane + 1 < kDiscOut);
+                const float dd = (s0 < 0.0f) ? -d0 : d0;
+                U[0] = __ballot(vote_ok && dd > 0.0f);
+                D[0] = __ballot(vote_ok && dd < 0.0f);
+                if (nf > 64) {
+                    lds_barrier();                               // B
+                    U[1] = uni64(sh.up[1]); D[1] = uni64(sh.dn[1]);
+                    U[2] = uni64(sh.up[2]); D[2] = uni64(sh.dn[2]);
+                } else {
+                    wave_fence();
                 }
             }
             STAMP(1);
@@ -193,16 +195,11 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int k = lane + 64 * r;
-                if (k < naccept && (m_idx + k) >= 0) my.h[8 + m_idx + k] = sv[r];
+                if (k < naccept && (m_idx + k) >= 0) my.h[8 + m_idx + k] = sh.sums[k];
             }
             m_idx += naccept;
-            {
-                const int last = naccept - 1, lr = last >> 6, ll = last & 63;
-                const float s0 = bcast_lane(sv[0], ll), s1 = bcast_lane(sv[1], ll), s2 = bcast_lane(sv[2], ll);
-                const float d0 = bcast_lane(dv[0], ll), d1 = bcast_lane(dv[1], ll), d2 = bcast_lane(dv[2], ll);
-                sum = (lr == 0) ? s0 : (lr == 1 ? s1 : s2);
-                dif = (lr == 0) ? d0 : (lr == 1 ? d1 : d2);
-            }
+            sum = unif(sh.sums[naccept - 1]);
+            dif = unif(sh.difs[naccept - 1]);
             if (kstar >= 0) {
                 thr = 0; clk = 0;
                 if (ts > thresh) {
@@ -342,6 +339,9 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
 #ifdef M17_STAMPS
     if (chan == 0 && lane == 0) for (int i = 0; i < 12; ++i) g_stamps[i] = acc_[i];
 #endif
+
+    if (lane == 0) sh.go = 0;
+    lds_barrier();                                           // A: helpers leave
 
     // ---- store state
     if (lane == 0) {

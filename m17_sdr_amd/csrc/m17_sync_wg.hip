@@ -134,33 +134,32 @@ __device__ __forceinline__ SyncResult sync_check_wave(const float v[8])
 // m17_rx_sync.cpp:25-31: bare first product, then += in ascending tap order, separate
 // multiply and add).  31 taps in four groups of 8 (last: 7); the next group's LDS reads
 // (taps are wave-uniform broadcasts) are issued before the current group's chain.
-__device__ __forceinline__ void fir_instant(const float *xs, const float4 *mf4, const float4 *md4, float &s, float &d)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// tp4: the branch's 32 (matched, derivative) tap pairs = 16 float4 (md4 is unused: kept for call compatibility)
+__device__ __forceinline__ void fir_instant(const float *xs, const float4 *tp4, const float4 *, float &s, float &d)
 {
+    // Packed form: lane pair (s, d) = (matched, derivative) accumulators, one v_pk_mul_f32 and
+    // one v_pk_add_f32 per tap -- the two chains of the reference advance in lock step, each
+    // still in its own ascending order with separate multiply and add.  Taps sit in LDS as
+    // (mf, md) pairs so a ds_read_b128 delivers two ready register pairs.
     const float2 *xp = reinterpret_cast<const float2 *>(xs);
-    float4 ma = mf4[0], mb = mf4[1], da = md4[0], db = md4[1];
-    float2 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
+    float2 xv[15];
+    float4 tp[16];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float4 nma = ma, nmb = mb, nda = da, ndb = db;
-        float2 y0 = x0, y1 = x1, y2 = x2, y3 = x3;
-        if (g < 3) {
-            nma = mf4[2 * g + 2]; nmb = mf4[2 * g + 3]; nda = md4[2 * g + 2]; ndb = md4[2 * g + 3];
-            y0 = xp[4 * g + 4]; y1 = xp[4 * g + 5]; y2 = xp[4 * g + 6];
-            if (g < 2) y3 = xp[4 * g + 7];
-            else { y3.x = xs[30]; y3.y = 0.0f; }
-        }
-        if (g == 0) { s = x0.x * ma.x; d = x0.x * da.x; }    // bare first product
-        else        { s += x0.x * ma.x; d += x0.x * da.x; }
-        s += x0.y * ma.y; d += x0.y * da.y;
-        s += x1.x * ma.z; d += x1.x * da.z;
-        s += x1.y * ma.w; d += x1.y * da.w;
-        s += x2.x * mb.x; d += x2.x * db.x;
-        s += x2.y * mb.y; d += x2.y * db.y;
-        s += x3.x * mb.z; d += x3.x * db.z;
-        if (g < 3) { s += x3.y * mb.w; d += x3.y * db.w; }   // tap 31 does not exist
-        ma = nma; mb = nmb; da = nda; db = ndb;
-        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+    for (int q = 0; q < 16; ++q) tp[q] = tp4[q];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) xv[q] = xp[q];
+    const float xl = xs[30];
+    v2f acc = (v2f){xv[0].x, xv[0].x} * (v2f){tp[0].x, tp[0].y};          // bare first product
+    acc = acc + (v2f){xv[0].y, xv[0].y} * (v2f){tp[0].z, tp[0].w};
+#pragma unroll
+    for (int q = 1; q < 15; ++q) {
+        acc = acc + (v2f){xv[q].x, xv[q].x} * (v2f){tp[q].x, tp[q].y};
+        acc = acc + (v2f){xv[q].y, xv[q].y} * (v2f){tp[q].z, tp[q].w};
     }
+    acc = acc + (v2f){xl, xl} * (v2f){tp[15].x, tp[15].y};
+    s = acc.x; d = acc.y;
 }
 
 __global__ __launch_bounds__(WG_T, 2)     // 1,024 channels x 2 waves = 2 waves per SIMD: <= 256 VGPRs, no spills
@@ -180,8 +179,9 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
 
     // ---- tables and state into LDS / uniform registers
     for (int q = t; q < kPhases * 32; q += WG_T) {
-        (&sh.mf[0][0])[q] = (&c_tab.mf[0][0])[q];
-        (&sh.md[0][0])[q] = (&c_tab.md[0][0])[q];
+        // taps interleaved as (matched, derivative) pairs: row idx = 64 floats starting at &sh.mf[0][0] + 64 idx
+        (&sh.mf[0][0])[2 * q] = (&c_tab.mf[0][0])[q];
+        (&sh.mf[0][0])[2 * q + 1] = (&c_tab.md[0][0])[q];
     }
     int clk = uni(cs.clk), thr = uni(cs.thr), index = uni(cs.index);
     float sum = unif(cs.sum), dif = unif(cs.dif);
@@ -267,7 +267,7 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
             }
             DBGCNT(0);
             if (go) {
-                const float4 *fmf4 = reinterpret_cast<const float4 *>(sh.mf[index]);
+                const float4 *fmf4 = reinterpret_cast<const float4 *>(&sh.mf[0][0] + 64 * index);
                 const float4 *fmd4 = reinterpret_cast<const float4 *>(sh.md[index]);
 #pragma unroll 3          // three instants in flight per thread: six independent add chains hide the VALU latency
                 for (int r = 0; r < 768 / WG_T; ++r) {
@@ -419,7 +419,7 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
             if (w * 64 < nf) {                                  // wave-uniform: this wave has instants to evaluate
                 const int a = xoff + (have ? ik : p);
                 const float *xs = (a & 1) ? (sh.xb + (a - 1)) : (sh.xa + a);
-                fir_instant(xs, reinterpret_cast<const float4 *>(sh.mf[index]),
+                fir_instant(xs, reinterpret_cast<const float4 *>(&sh.mf[0][0] + 64 * index),
                             reinterpret_cast<const float4 *>(sh.md[index]), s, d);
             }
             STAMP(1);

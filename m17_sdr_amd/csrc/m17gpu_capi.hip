@@ -3,6 +3,7 @@
 #include "m17_kernels.hip"
 #include "m17_sync_wg.hip"
 #include "m17_sync_wave.hip"
+#include "m17_sync_ch.hip"
 #include "m17_host.h"
 #include "../../include/m17gpu.h"
 #include <string>
@@ -82,8 +83,9 @@ int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc,
                     int update_state, hipStream_t st)
 {
     const int total = ctx->C * nblk;
-    // one lane per channel-block needs >= ~2 waves per SIMD to run at rate: 131,072 channel-blocks
-    const bool quad = ctx->fe_impl == 2 || ctx->fe_impl >= 100 || (ctx->fe_impl == 0 && total < 131072);
+    // measured on MI355X (scripts/exp_scale.py): the 4-lane kernel wins at 51,200 .. 196,608 channel-blocks,
+    // so it is the default at every size; fe_impl 1 keeps the one-lane kernel selectable
+    const bool quad = ctx->fe_impl != 1;
 #define LAUNCH_FQ(ABL) hipLaunchKernelGGL(k_frontend_q<ABL>, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st, \
                            reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, disc, offs, nblk, total, update_state)
     if (ctx->fe_impl >= 100) {          // timing-only ablations of k_frontend_q (results are wrong)
@@ -104,7 +106,13 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
                       m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, float *d_syms, int32_t *d_nsyms,
                       hipStream_t st, int ext_lock = -1)
 {
-    if (ctx->sync_impl == 2)
+    if (ctx->sync_impl == 3)
+        hipLaunchKernelGGL(k_sync_frame_ch, dim3(ctx->C), dim3(64 * CH_WAVES), 0, st,
+                           disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
+                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
+                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
+                           ctx->d_fsym, ctx->d_work, ctx->d_nwork);
+    else if (ctx->sync_impl == 2)
         hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(ctx->C, SW_WAVES)), dim3(64 * SW_WAVES), 0, st,
                            disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
