@@ -1,0 +1,171 @@
+// m17_decode_chan.hip -- k_decode_chan: frame decode + per-channel bookkeeping, one
+// 256-thread workgroup per channel (included after m17_kernels.hip).
+//
+// Part 1 decodes the frames k_sync_frame queued for this channel, 16 at a time with 16
+// lanes per frame (decode_frame16: demap, fused gather, one-state-per-lane Viterbi,
+// Golay, packers).  Indexing frames by (channel, record) needs no global work list --
+// a returning atomicAdd per frame in the sequential framer cost 5 us each.
+// Part 2 replays the channel's records in event order for what m17_rx_parse does to
+// file-static state: LICH reassembly with its CRC, the delivery gate, the LSF gate quirk,
+// packet reassembly, the m17_dbase counters (m17_rx_parse.cpp:34-101,144-158;
+// m17_dbase.cpp:60-82).  One wave runs it with uniform control flow; the 30-byte CRC is
+// evaluated across 30 lanes: CRC-16 is linear over GF(2), so crc(msg) = crc(30 zero bytes)
+// xor XOR_i XOR_{bit k of msg[i]} E[i][k] with 240 precomputed basis words.
+#pragma clang fp contract(off)
+
+namespace m17dev {
+
+__device__ __forceinline__ uint32_t xor_reduce32(uint32_t v)      // over lanes 0..31 of a wave
+{
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) v ^= (uint32_t)__shfl_xor((int)v, off, 64);
+    return v;
+}
+
+// CRC-16/M17 (m17_crc.cpp:26-35) of 30 bytes held in LDS, computed by lanes 0..29
+__device__ __forceinline__ uint32_t crc30_wave(const uint8_t *p, const uint16_t *basis, int lane)
+{
+    uint32_t v = 0;
+    if (lane < 30) {
+        const uint32_t b = p[lane];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v ^= (b >> k & 1u) ? (uint32_t)basis[lane * 8 + k] : 0u;
+    }
+    v = xor_reduce32(v);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(v ^ 0x1B73u));   // 0x1B73 = crc of 30 zero bytes
+}
+
+struct LsfShared {
+    uint16_t basis[240];
+    uint16_t crc[256];
+    uint8_t  lsf[2][32];
+    uint8_t  packet[800];
+};
+
+__global__ __launch_bounds__(256)
+void k_decode_chan(const float *__restrict__ fsym, ChanState *__restrict__ st,
+                   m17gpu_rec_dev *__restrict__ recs, int rec_cap, const int32_t *__restrict__ counts,
+                   const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr,
+                   const uint16_t *__restrict__ crc_basis)
+{
+    __shared__ __attribute__((aligned(16))) DecShared sh_all[DEC_FRAMES_PER_WG];
+    __shared__ LsfShared ls;
+    const int t = (int)threadIdx.x, g = t >> 4, ln = t & 15;
+    const int chan = (int)blockIdx.x;
+    ChanState &cs = st[chan];
+    m17gpu_rec_dev *crecs = recs + (size_t)chan * rec_cap;
+    const int n = min(counts[chan], rec_cap);
+
+    if (t < 240) ls.basis[t] = crc_basis[t];
+    ls.crc[t] = c_tab.crc[t];
+    if (t < 64) reinterpret_cast<uint32_t *>(ls.lsf)[t & 15] = reinterpret_cast<const uint32_t *>(cs.lsf)[t & 15];
+    if (t < 200) reinterpret_cast<uint32_t *>(ls.packet)[t] = reinterpret_cast<const uint32_t *>(cs.packet)[t];
+
+    // ---- part 1: decode
+    DecShared &sh = sh_all[g];
+    for (int base = 0; base < n; base += DEC_FRAMES_PER_WG) {
+        const int item = base + g;
+        const bool active = item < n;
+        const int it = active ? item : n - 1;
+        m17gpu_rec_dev &rec = crecs[it];
+        int type = (int)rec.type;
+        const bool decodable = active && (rec.flags & M17_F_PARSED) && type >= 1 && type <= 3;
+        // the 4 groups of a wave share ballot / bpermute instructions: a group without work
+        // decodes its (valid) slot anyway and does not write back
+        if (!(type >= 1 && type <= 3)) type = 1;
+        const float *src = fsym + ((size_t)chan * rec_cap + it) * kFrameSyms;
+        if (__ballot(decodable) != 0ull) {
+            for (int q = ln; q < kFrameSyms; q += 16) sh.dep[q] = decodable ? src[q] : 0.25f;
+            if (ln < 8) reinterpret_cast<uint32_t *>(sh.bytes)[ln] = 0;
+            group_sync();
+            uint32_t fn, ge;
+            decode_frame16(sh, type, ln, genc, gerr, fn, ge);
+            if (decodable) {
+                uint32_t *r = reinterpret_cast<uint32_t *>(&rec);
+                if (ln < 8) r[5 + ln] = reinterpret_cast<const uint32_t *>(sh.bytes)[ln];
+                if (ln == 8) {
+                    r[0] = (r[0] & 0xFF00FFFFu) | ((ge & 0xFF) << 16);
+                    r[1] = (r[1] & 0x0000FFFFu) | (fn << 16);
+                }
+            }
+            group_sync();
+        }
+    }
+    __syncthreads();                     // records complete and visible to wave 0 (same CU)
+
+    // ---- part 2: in-order bookkeeping by wave 0, uniform control flow
+    if (t >= 64) return;
+    const int lane = t;
+    uint32_t g_errors = (uint32_t)uni((int)cs.g_errors), n_frames = (uint32_t)uni((int)cs.n_frames);
+    uint32_t in_frame = (uint32_t)uni((int)cs.in_frame), epoch = (uint32_t)uni((int)cs.frame_id_epoch);
+    int packet_idx = uni(cs.packet_idx);
+    bool lsf1_ok = crc30_wave(ls.lsf[1], ls.basis, lane) == 0;          // m_lsf[1] only ever changes to CRC-good content
+    bool gate_ok = crc30_wave(ls.packet, ls.basis, lane) == 0;           // decode_link_frame's quirk (m17_rx_parse.cpp:98)
+    for (int i = 0; i < n; ++i) {
+        const uint32_t *r = reinterpret_cast<const uint32_t *>(&crecs[i]);
+        // lanes 0..15 fetch the record words, everything below is wave-uniform
+        const uint32_t wv = (lane < 16) ? r[lane] : 0u;
+        const uint32_t w0 = (uint32_t)bcast_lane_i((int)wv, 0), w1 = (uint32_t)bcast_lane_i((int)wv, 1);
+        uint32_t flags = w1 & 0xFFFF;
+        const int type = (int)(w0 & 0xFF);
+        if (flags & M17_F_AOS) { g_errors = 0; n_frames = 0; in_frame = 1; epoch++; continue; }
+        if (flags & (M17_F_EOT | M17_F_LOST)) { in_frame = 0; epoch++; continue; }
+        if (!(flags & M17_F_PARSED)) continue;
+        const uint32_t old_flags = flags;
+        if (type == 0 || type == 5) {
+            epoch++;
+        } else if (type == 1) {
+            if (gate_ok) flags |= M17_F_LSF_GATE;
+        } else if (type == 2) {
+            g_errors += (w0 >> 16) & 0xFF; n_frames++;
+            // update_lich (m17_rx_parse.cpp:71-85): data[0..5] = words 5 and low half of 6
+            const uint32_t d0 = (uint32_t)bcast_lane_i((int)wv, 5), d1 = (uint32_t)bcast_lane_i((int)wv, 6);
+            const int seq = (int)((d1 >> 8 & 0xFF) >> 5);
+            if (seq < 6) {
+                if (lane < 5) ls.lsf[0][seq * 5 + lane] = (uint8_t)((lane < 4) ? (d0 >> (8 * lane)) : d1);
+                group_sync();
+                if (crc30_wave(ls.lsf[0], ls.basis, lane) == 0) {
+                    if (lane < 30) ls.lsf[1][lane] = ls.lsf[0][lane];
+                    group_sync();
+                    lsf1_ok = true;
+                    flags |= M17_F_LICH_OK;
+                }
+            }
+            if (lsf1_ok) flags |= M17_F_DELIVERED;                          // :148
+        } else if (type == 3) {
+            // parse_packet (m17_rx_parse.cpp:34-51); data bytes live in words 5..11
+            const uint32_t d25 = ((uint32_t)bcast_lane_i((int)wv, 11) >> 8) & 0xFF;      // data[25]
+            const int eof = (int)(d25 >> 7), fnv = (int)((d25 >> 2) & 0x1F);
+            const uint8_t *dbytes = reinterpret_cast<const uint8_t *>(r + 5);
+            if (eof) {
+                int cnt = fnv;
+                if (packet_idx + cnt > 800) cnt = 800 - packet_idx;
+                if (lane < cnt) ls.packet[packet_idx + lane] = dbytes[lane];
+                packet_idx += cnt;
+                group_sync();
+                uint32_t crc = 0xFFFF;                                        // variable length: table-driven, lane-uniform
+                for (int k = 0; k < packet_idx; ++k)
+                    crc = ((crc << 8) ^ ls.crc[((crc >> 8) ^ ls.packet[k]) & 0xFF]) & 0xFFFF;
+                if (crc == 0) flags |= M17_F_PKT_VALID;
+                packet_idx = 0;
+            } else {
+                if (lane < 25) ls.packet[fnv * 25 + lane] = dbytes[lane];
+                packet_idx = fnv * 25;
+                group_sync();
+            }
+            gate_ok = crc30_wave(ls.packet, ls.basis, lane) == 0;
+        }
+        if (flags != old_flags && lane == 0)
+            reinterpret_cast<uint32_t *>(&crecs[i])[1] = (w1 & 0xFFFF0000u) | flags;
+    }
+    // ---- state back
+    if (lane == 0) {
+        cs.g_errors = g_errors; cs.n_frames = n_frames; cs.in_frame = in_frame; cs.frame_id_epoch = epoch;
+        cs.packet_idx = packet_idx;
+    }
+    group_sync();
+    if (lane < 16) reinterpret_cast<uint32_t *>(cs.lsf)[lane] = reinterpret_cast<const uint32_t *>(ls.lsf)[lane];
+    for (int q = lane; q < 200; q += 64) reinterpret_cast<uint32_t *>(cs.packet)[q] = reinterpret_cast<const uint32_t *>(ls.packet)[q];
+}
+
+} // namespace m17dev

@@ -694,7 +694,7 @@ void k_sync_frame(const float *__restrict__ disc,     // [C][nblk][384]
                     if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
                         float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kFrameSyms;
                         for (int q = lane; q < kFrameSyms; q += 64) fd[q] = sh.f[q];
-                        if (lane == 0) work[atomicAdd(nwork, 1)] = chan * rec_cap + nrec;
+                        if (work && lane == 0) work[atomicAdd(nwork, 1)] = chan * rec_cap + nrec;
                     }
                     nrec++;
                     if (unlock) {
@@ -767,9 +767,8 @@ void k_sync_frame(const float *__restrict__ disc,     // [C][nblk][384]
 constexpr int DEC_FRAMES_PER_WG = 16;          // 256 threads
 
 struct DecShared {
-    float sym[kFrameSyms];
     float soft[kSoftBits];
-    float dep[488];
+    float dep[488];                 // first holds the 192 frame symbols (dead once demapped), then the de-punctured soft bits
     uint16_t dec[244];
     uint8_t bits[248];
     uint8_t bytes[32];
@@ -867,7 +866,7 @@ __device__ void decode_frame16(DecShared &sh, int type, int ln,
                                const uint16_t *genc, const uint16_t *gerr,
                                uint32_t &fn_out, uint32_t &gerrs_out)
 {
-    demap16(sh.sym, sh.soft, ln);
+    demap16(sh.dep, sh.soft, ln);
     group_sync();
     const int len = c_tab.glen[type];
     // fused m17_de_correlate_1 . m17_de_interleave . m17_de_punc_pN (m17_rx_parse.cpp:90-94 etc.)
@@ -934,7 +933,7 @@ void k_decode(const float *__restrict__ fsym, const int32_t *__restrict__ work,
         const bool decodable = type >= 1 && type <= 3;
         if (!decodable) type = 1;
         const float *src = fsym + (size_t)slot * kFrameSyms;
-        for (int q = ln; q < kFrameSyms; q += 16) sh.sym[q] = src[q];
+        for (int q = ln; q < kFrameSyms; q += 16) sh.dep[q] = src[q];
         if (ln < 8) reinterpret_cast<uint32_t *>(sh.bytes)[ln] = 0;
         group_sync();
         uint32_t fn, ge;
@@ -978,9 +977,9 @@ void k_demap(const float *__restrict__ sym, float *__restrict__ soft, int n)
     const bool active = item < n;
     const int it = active ? item : n - 1;
     DecShared &sh = sh_all[g];
-    for (int q = ln; q < kFrameSyms; q += 16) sh.sym[q] = sym[(size_t)it * kFrameSyms + q];
+    for (int q = ln; q < kFrameSyms; q += 16) sh.dep[q] = sym[(size_t)it * kFrameSyms + q];
     group_sync();
-    demap16(sh.sym, sh.soft, ln);
+    demap16(sh.dep, sh.soft, ln);
     group_sync();
     if (active)
         for (int q = ln; q < kSoftBits; q += 16) soft[(size_t)it * kSoftBits + q] = sh.soft[q];

@@ -265,7 +265,7 @@ void k_sync_frame_ch(const float *__restrict__ disc,     // [C][nblk][384]
                         float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kFrameSyms;
 #pragma unroll
                         for (int q = 0; q < 3; ++q) fd[lane + 64 * q] = my.f[lane + 64 * q];
-                        if (lane == 0) work[atomicAdd(nwork, 1)] = chan * rec_cap + nrec;
+                        if (work && lane == 0) work[atomicAdd(nwork, 1)] = chan * rec_cap + nrec;
                     }
                     nrec++;
                     if (unlock) {

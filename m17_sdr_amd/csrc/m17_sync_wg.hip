@@ -349,7 +349,7 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
                     }
                     if (mode == 1) {
                         int wbase = 0;
-                        if (t == 0) {
+                        if (work && t == 0) {
                             int nq = 0;
                             for (int q = 0; q < brem; ++q) {
                                 const int ty = sh.fr_type[q];
@@ -520,7 +520,7 @@ void k_sync_frame_wg(const float *__restrict__ disc,     // [C][nblk][384]
                     if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
                         float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kFrameSyms;
                         for (int q = t; q < kFrameSyms; q += WG_T) fd[q] = sh.f[q];
-                        if (t == 0) work[atomicAdd(nwork, 1)] = chan * rec_cap + nrec;
+                        if (work && t == 0) work[atomicAdd(nwork, 1)] = chan * rec_cap + nrec;
                     }
                     nrec++;
                     if (unlock) {

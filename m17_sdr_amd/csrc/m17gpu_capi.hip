@@ -4,6 +4,7 @@
 #include "m17_sync_wg.hip"
 #include "m17_sync_wave.hip"
 #include "m17_sync_ch.hip"
+#include "m17_decode_chan.hip"
 #include "m17_host.h"
 #include "../../include/m17gpu.h"
 #include <string>
@@ -25,7 +26,8 @@ struct m17gpu_ctx {
     ChanState *d_state = nullptr;
     float *d_disc = nullptr, *d_offs = nullptr, *d_fsym = nullptr;
     int32_t *d_work = nullptr, *d_nwork = nullptr, *d_counts = nullptr;
-    uint16_t *d_genc = nullptr, *d_gerr = nullptr;
+    uint16_t *d_genc = nullptr, *d_gerr = nullptr, *d_crc_basis = nullptr;
+    int decode_impl = 1;                     // 1 = workgroup per channel (decode + bookkeeping), 0 = work list + k_lsf
     bool profiling = false;
     int fe_impl = 0;                         // 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block
     int sync_impl = 2;                       // 2 = wave per channel (default), 1 = workgroup per channel, 0 = first version
@@ -73,6 +75,16 @@ int upload_tables(m17gpu_ctx *ctx)
     HIPCHK(hipMalloc(&ctx->d_gerr, 4096 * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(ctx->d_genc, T.golay_enc, 4096 * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->d_gerr, T.golay_err, 4096 * sizeof(uint16_t), hipMemcpyHostToDevice));
+    // CRC-16 basis for the lane-parallel 30-byte CRC: word of a message whose only set bit is bit k of byte i
+    uint16_t basis[240];
+    for (int i = 0; i < 30; ++i)
+        for (int k = 0; k < 8; ++k) {
+            uint8_t msg[30] = {0};
+            msg[i] = (uint8_t)(1u << k);
+            basis[i * 8 + k] = (uint16_t)(m17::crc16(msg, 30) ^ 0x1B73);    // remove the init-value term
+        }
+    HIPCHK(hipMalloc(&ctx->d_crc_basis, sizeof basis));
+    HIPCHK(hipMemcpy(ctx->d_crc_basis, basis, sizeof basis, hipMemcpyHostToDevice));
     return M17GPU_OK;
 }
 
@@ -106,30 +118,31 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
                       m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, float *d_syms, int32_t *d_nsyms,
                       hipStream_t st, int ext_lock = -1)
 {
+    int32_t *wl = ctx->decode_impl == 0 ? ctx->d_work : nullptr;      // the work list exists only for the legacy decode path
     if (ctx->sync_impl == 3)
         hipLaunchKernelGGL(k_sync_frame_ch, dim3(ctx->C), dim3(64 * CH_WAVES), 0, st,
                            disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
-                           ctx->d_fsym, ctx->d_work, ctx->d_nwork);
+                           ctx->d_fsym, wl, ctx->d_nwork);
     else if (ctx->sync_impl == 2)
         hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(ctx->C, SW_WAVES)), dim3(64 * SW_WAVES), 0, st,
                            disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
-                           ctx->d_fsym, ctx->d_work, ctx->d_nwork);
+                           ctx->d_fsym, wl, ctx->d_nwork);
     else if (ctx->sync_impl == 1 || ext_lock >= 0)
         hipLaunchKernelGGL(k_sync_frame_wg, dim3(ctx->C), dim3(WG_T), 0, st,
                            disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
-                           ctx->d_fsym, ctx->d_work, ctx->d_nwork, ctx->allow_fast);
+                           ctx->d_fsym, wl, ctx->d_nwork, ctx->allow_fast);
     else
         hipLaunchKernelGGL(k_sync_frame, dim3(cdiv(ctx->C, SF_WAVES)), dim3(64 * SF_WAVES), 0, st,
                            disc, offs, ctx->d_state, ctx->C, nblk, mode,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
-                           ctx->d_fsym, ctx->d_work, ctx->d_nwork);
+                           ctx->d_fsym, wl, ctx->d_nwork);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -191,7 +204,7 @@ void m17gpu_destroy(m17gpu_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     void *bufs[] = {ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->d_fsym, ctx->d_work,
-                    ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr};
+                    ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis};
     for (void *p : bufs) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -236,19 +249,28 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
                                 d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
     MARK(2);
     if ((mode & 0xFF) == 1) {
-        const long long slots = (long long)ctx->C * rec_cap;
-        int grid = cdiv(slots, DEC_FRAMES_PER_WG);
-        if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(k_decode, dim3(grid), dim3(256), 0, st, ctx->d_fsym, ctx->d_work, ctx->d_nwork,
-                           (int)slots, (const uint8_t *)nullptr, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
-                           ctx->d_genc, ctx->d_gerr);
-        HIPCHK(hipGetLastError());
-        MARK(3);
-        hipLaunchKernelGGL(k_lsf, dim3(cdiv(ctx->C, 64)), dim3(64), 0, st, ctx->d_state, ctx->C,
-                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap,
-                           d_counts ? d_counts : ctx->d_counts);
-        HIPCHK(hipGetLastError());
-        MARK(4);
+        int32_t *cnt = d_counts ? d_counts : ctx->d_counts;
+        if (ctx->decode_impl == 1) {
+            hipLaunchKernelGGL(k_decode_chan, dim3(ctx->C), dim3(256), 0, st, ctx->d_fsym, ctx->d_state,
+                               reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->d_genc, ctx->d_gerr,
+                               ctx->d_crc_basis);
+            HIPCHK(hipGetLastError());
+            MARK(3);
+            MARK(4);
+        } else {
+            const long long slots = (long long)ctx->C * rec_cap;
+            int grid = cdiv(slots, DEC_FRAMES_PER_WG);
+            if (grid > 4096) grid = 4096;
+            hipLaunchKernelGGL(k_decode, dim3(grid), dim3(256), 0, st, ctx->d_fsym, ctx->d_work, ctx->d_nwork,
+                               (int)slots, (const uint8_t *)nullptr, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
+                               ctx->d_genc, ctx->d_gerr);
+            HIPCHK(hipGetLastError());
+            MARK(3);
+            hipLaunchKernelGGL(k_lsf, dim3(cdiv(ctx->C, 64)), dim3(64), 0, st, ctx->d_state, ctx->C,
+                               reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap, cnt);
+            HIPCHK(hipGetLastError());
+            MARK(4);
+        }
     }
 #undef MARK
     return M17GPU_OK;
@@ -294,6 +316,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     if (!std::strcmp(name, "sync_impl")) ctx->sync_impl = value;
     else if (!std::strcmp(name, "fast_windows")) ctx->allow_fast = value;
     else if (!std::strcmp(name, "fe_impl")) ctx->fe_impl = value;
+    else if (!std::strcmp(name, "decode_impl")) ctx->decode_impl = value;
     else return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: unknown option ") + name);
     return M17GPU_OK;
 }
