@@ -169,6 +169,7 @@ typedef struct {
     int32_t  delay_samples;   /* un-modulated carrier samples prepended (0..1919) */
     float    ebn0_db;         /* AWGN level; >= 100 means noiseless */
     int32_t  packet_mode;     /* 0 = stream transmissions, 1 = packet-mode bursts */
+    float    noise_cutoff_hz; /* 0 = white noise over 48 kHz; >0 = one-sided cutoff of the channel filter on the noise */
 } m17gen_params;
 
 /* h_iq [nblk*1920*2]; h_lsf [30] the LSF sent (incl. CRC); h_payload
@@ -180,7 +181,7 @@ int m17gen_channel(const m17gen_params *p, int nblk, int16_t *h_iq,
  * h_iq [C][nblk][1920][2]; h_lsf [C][30]; h_payload [C][max_payload_frames][16];
  * h_nframes [C]; nthreads host threads. */
 int m17gen_batch(int C, uint64_t base_seed, int first_channel, int nblk, int n_stream_frames,
-                 float ebn0_db, int packet_mode, int16_t *h_iq, uint8_t *h_lsf,
+                 float ebn0_db, float noise_cutoff_hz, int packet_mode, int16_t *h_iq, uint8_t *h_lsf,
                  uint8_t *h_payload, int max_payload_frames, int32_t *h_nframes, int nthreads);
 /* transmit-side codec pieces, exposed for round-trip tests */
 int m17gen_stream_frame_dibits(const uint8_t lsf[30], int lich_count, uint16_t fn,

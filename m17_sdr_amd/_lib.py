@@ -34,7 +34,7 @@ class Rec(C.Structure):
 
 class GenParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_stream_frames", C.c_int32), ("delay_samples", C.c_int32),
-                ("ebn0_db", C.c_float), ("packet_mode", C.c_int32)]
+                ("ebn0_db", C.c_float), ("packet_mode", C.c_int32), ("noise_cutoff_hz", C.c_float)]
 
 
 # name -> (restype, argtypes); every symbol include/m17gpu.h declares
@@ -64,7 +64,7 @@ SIGNATURES = {
     "m17gpu_get_taps": (_i, [_vp, _vp]),
     "m17gpu_get_golay_tables": (_i, [_vp, _vp]),
     "m17gen_channel": (_i, [C.POINTER(GenParams), _i, _vp, _vp, _vp, _i]),
-    "m17gen_batch": (_i, [_i, _u64, _i, _i, _i, C.c_float, _i, _vp, _vp, _vp, _i, _vp, _i]),
+    "m17gen_batch": (_i, [_i, _u64, _i, _i, _i, C.c_float, C.c_float, _i, _vp, _vp, _vp, _i, _vp, _i]),
     "m17gen_stream_frame_dibits": (_i, [_vp, _i, C.c_uint16, _vp, _vp]),
     "m17gen_lsf_frame_dibits": (_i, [_vp, _vp]),
     "m17gen_packet_frame_dibits": (_i, [_vp, _i, _i, _i, _vp]),

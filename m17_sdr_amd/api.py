@@ -166,13 +166,14 @@ class Receiver:
         return a
 
 
-def generate_channel(seed, nblk, n_stream_frames=40, delay=0, ebn0_db=200.0, packet_mode=0, max_frames=None):
+def generate_channel(seed, nblk, n_stream_frames=40, delay=0, ebn0_db=200.0, packet_mode=0, max_frames=None,
+                     noise_cutoff_hz=0.0):
     """Host signal source for one channel: (iq[nblk,1920,2] int16, lsf[30], payloads[n,16], n)."""
     max_frames = max_frames or (nblk + 2)
     iq = np.zeros((nblk, 1920, 2), np.int16)
     lsf = np.zeros(30, np.uint8)
     pl = np.zeros((max_frames, 16), np.uint8)
-    p = _lib.GenParams(seed, n_stream_frames, delay, ebn0_db, packet_mode)
+    p = _lib.GenParams(seed, n_stream_frames, delay, ebn0_db, packet_mode, noise_cutoff_hz)
     n = lib().m17gen_channel(C.byref(p), nblk, iq.ctypes.data_as(C.c_void_p), lsf.ctypes.data_as(C.c_void_p),
                              pl.ctypes.data_as(C.c_void_p), max_frames)
     if n < 0:
@@ -181,14 +182,15 @@ def generate_channel(seed, nblk, n_stream_frames=40, delay=0, ebn0_db=200.0, pac
 
 
 def generate_batch(n_channels, nblk, n_stream_frames=40, ebn0_db=200.0, base_seed=0x4D313700,
-                   first_channel=0, packet_mode=0, nthreads=8, out=None):
+                   first_channel=0, packet_mode=0, nthreads=8, out=None, noise_cutoff_hz=0.0):
     """Host signal source for C channels: dict(iq[C,nblk,1920,2], lsf[C,30], payload[C,F,16], nframes[C])."""
     max_frames = nblk + 2
     iq = out if out is not None else np.zeros((n_channels, nblk, 1920, 2), np.int16)
     lsf = np.zeros((n_channels, 30), np.uint8)
     pl = np.zeros((n_channels, max_frames, 16), np.uint8)
     nf = np.zeros((n_channels,), np.int32)
-    rc = lib().m17gen_batch(n_channels, base_seed, first_channel, nblk, n_stream_frames, ebn0_db, packet_mode,
+    rc = lib().m17gen_batch(n_channels, base_seed, first_channel, nblk, n_stream_frames, ebn0_db, noise_cutoff_hz,
+                            packet_mode,
                             iq.ctypes.data_as(C.c_void_p), lsf.ctypes.data_as(C.c_void_p),
                             pl.ctypes.data_as(C.c_void_p), max_frames, nf.ctypes.data_as(C.c_void_p), nthreads)
     if rc != 0:

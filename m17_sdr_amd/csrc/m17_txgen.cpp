@@ -151,11 +151,39 @@ void random_call(SplitMix64 &rng, char call[10])
     call[9] = 0;
 }
 
-void add_awgn(std::vector<int16_t> &iq, double sigma, SplitMix64 &rng)
+// AWGN of complex variance 2*sigma^2 per 48 kHz sample (PSD N0), optionally band-limited
+// by a unity-gain windowed-sinc low-pass of one-sided cutoff `cutoff_hz` -- the channel
+// filter a radio front end has ahead of the ADC (the reference itself has none in software,
+// m17_dsp.cpp:461-476).  0 = white over the whole 48 kHz.
+void add_awgn(std::vector<int16_t> &iq, double sigma, SplitMix64 &rng, double cutoff_hz)
 {
+    const size_t n = iq.size() / 2;
+    std::vector<double> nr(n), ni(n);
+    for (size_t i = 0; i < n; ++i) rng.gauss2(nr[i], ni[i]);
+    if (cutoff_hz > 0.0) {
+        constexpr int L = 63;
+        double h[L], hs = 0.0;
+        const double fc = cutoff_hz / 48000.0;
+        for (int k = 0; k < L; ++k) {
+            const int m = k - L / 2;
+            const double sinc = (m == 0) ? 2.0 * fc : std::sin(2.0 * M_PI * fc * m) / (M_PI * m);
+            h[k] = sinc * (0.54 - 0.46 * std::cos(2.0 * M_PI * k / (L - 1)));
+            hs += h[k];
+        }
+        for (int k = 0; k < L; ++k) h[k] /= hs;
+        std::vector<double> fr(n), fi(n);
+        for (size_t i = 0; i < n; ++i) {
+            double ar = 0.0, ai = 0.0;
+            for (int k = 0; k < L; ++k) {
+                const long j = (long)i + k - L / 2;
+                if (j >= 0 && j < (long)n) { ar += h[k] * nr[(size_t)j]; ai += h[k] * ni[(size_t)j]; }
+            }
+            fr[i] = ar; fi[i] = ai;
+        }
+        nr.swap(fr); ni.swap(fi);
+    }
     for (size_t i = 0; i + 1 < iq.size(); i += 2) {
-        double a, b;
-        rng.gauss2(a, b);
+        const double a = nr[i / 2], b = ni[i / 2];
         long re = std::lrint((double)iq[i] + sigma * a);
         long im = std::lrint((double)iq[i + 1] + sigma * b);
         re = std::min(32767l, std::max(-32767l, re));
@@ -330,14 +358,14 @@ int m17gen_channel(const m17gen_params *p, int nblk, int16_t *h_iq,
         const double a = 16383.0;
         const double sigma = std::sqrt(a * a * kOs / (2.0 * esn0));
         SplitMix64 nrng(p->seed ^ 0xA36E0000A36E0000ull);
-        add_awgn(iq, sigma, nrng);
+        add_awgn(iq, sigma, nrng, (double)p->noise_cutoff_hz);
     }
     std::memcpy(h_iq, iq.data(), sizeof(int16_t) * 2 * want);
     return sent;
 }
 
 int m17gen_batch(int C, uint64_t base_seed, int first_channel, int nblk, int n_stream_frames,
-                 float ebn0_db, int packet_mode, int16_t *h_iq, uint8_t *h_lsf,
+                 float ebn0_db, float noise_cutoff_hz, int packet_mode, int16_t *h_iq, uint8_t *h_lsf,
                  uint8_t *h_payload, int max_payload_frames, int32_t *h_nframes, int nthreads)
 {
     if (C <= 0 || nblk <= 0 || !h_iq) return M17GPU_ERR_ARG;
@@ -357,6 +385,7 @@ int m17gen_batch(int C, uint64_t base_seed, int first_channel, int nblk, int n_s
                 p.delay_samples = (int)(h.next() % 1920);
                 p.ebn0_db = ebn0_db;
                 p.packet_mode = packet_mode;
+                p.noise_cutoff_hz = noise_cutoff_hz;
                 int r = m17gen_channel(&p, nblk, h_iq + (size_t)c * chan_stride,
                                        h_lsf ? h_lsf + (size_t)c * 30 : nullptr,
                                        h_payload ? h_payload + (size_t)c * max_payload_frames * 16 : nullptr,

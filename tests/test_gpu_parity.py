@@ -168,3 +168,31 @@ def test_every_kernel_variant_is_bit_exact(options):
     _rx_compare(C=40, nblk=22, mode=1, ebn0=200.0, nsf=12, options=options)
     _rx_compare(C=40, nblk=9, mode=1, ebn0=9.0, nsf=5, calls=3, options=options)
     _rx_compare(C=9, nblk=1, mode=0, ebn0=15.0, calls=12, options=options)
+
+
+def test_awgn_sweep_curves_coincide_with_oracle():
+    """Config #4 in miniature: same IQ => identical records at every Eb/N0, and the payload
+    BER against the transmitted truth falls with Eb/N0 (band-limited noise, 12.5 kHz channel)."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    C, nblk = 192, 20
+    bers = []
+    for eb in (6.0, 10.0, 16.0):
+        sig = m.generate_batch(C, nblk, n_stream_frames=14, ebn0_db=eb, noise_cutoff_hz=6250.0)
+        rx = m.Receiver(C, nblk)
+        out = rx.rx_blocks(torch.from_numpy(sig["iq"]).cuda(), 1, rx.alloc_outputs(nblk))
+        torch.cuda.synchronize()
+        recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
+        counts = out["counts"].cpu().numpy()
+        ref = oracle.Channels(C).rx_blocks(sig["iq"], mode=1, want_syms=False)
+        np.testing.assert_array_equal(counts, ref["counts"])
+        err = bits = 0
+        for c in range(C):
+            assert recs[c, :counts[c]].tobytes() == ref["recs"][c, :counts[c]].tobytes()
+            for r in recs[c, :counts[c]]:
+                if r["type"] == 2 and (r["flags"] & m.F_PARSED) and r["fn"] < sig["nframes"][c]:
+                    err += int(np.unpackbits(np.bitwise_xor(sig["payload"][c, r["fn"]], r["data"][8:24])).sum())
+                    bits += 128
+        bers.append(err / max(bits, 1))
+        rx.close()
+    assert bers[0] > bers[1] > bers[2] and bers[2] < 5e-3, bers
