@@ -317,8 +317,9 @@ template <int ABL>      // ABL != 0: timing-only ablations (wrong results), see 
 __global__ __launch_bounds__(64 * FQ_WAVES)
 void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
                   float *__restrict__ disc_raw, float *__restrict__ offs,
-                  int nblk, int total, int update_state)
+                  int nblk, int total, int update_state, int b0, int cbk)
 {
+    // this launch covers blocks b0 .. b0+cbk-1 of every channel: total = C * cbk items
     __shared__ __attribute__((aligned(16))) uint32_t tile[FQ_WAVES][16 * FQ_STRIDE];  // raw IQ, then u*0.5
     __shared__ __attribute__((aligned(16))) float otile[FQ_WAVES][16 * FQ_STRIDE];    // 64 picked outputs per row
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();

@@ -65,7 +65,8 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                        ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
                        m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
                        float *__restrict__ syms, int32_t *__restrict__ nsyms,
-                       float *__restrict__ fsym, int32_t *__restrict__ work, int32_t *__restrict__ nwork)
+                       float *__restrict__ fsym, int32_t *__restrict__ work, int32_t *__restrict__ nwork,
+                       int b0, int bcount)          // this launch: blocks b0 .. b0+bcount-1 of a call of nblk blocks
 {
     __shared__ __attribute__((aligned(16))) SwShared sh;
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
@@ -93,7 +94,8 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
     if (lane < 8) my.h[lane] = cs.sync[lane];
 #pragma unroll
     for (int r = 0; r < 3; ++r) my.f[lane + 64 * r] = cs.fsym[lane + 64 * r];
-    int nrec = 0, sym_total = 0;
+    int nrec = (b0 == 0) ? 0 : uni(counts[chan]);
+    int sym_total = (b0 == 0) ? 0 : uni(cs.sym_total);
     const size_t sym_base = (size_t)chan * M17_SYM_STRIDE(nblk);
     const float *dsrc = disc + (size_t)chan * nblk * kDiscOut;
     const float *osrc = offs ? offs + (size_t)chan * nblk : nullptr;
@@ -101,10 +103,10 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
     // block 0 input (DC removed, m17_dsp.cpp:217-219); later blocks are prefetched
     float pf[6];
     {
-        const float off = osrc ? osrc[0] : 0.0f;
+        const float off = osrc ? osrc[b0] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            float v = dsrc[lane + 64 * r];
+            float v = dsrc[(size_t)b0 * kDiscOut + lane + 64 * r];
             if (osrc) v = v - off;
             my.xa[kTaps - 1 + lane + 64 * r] = v;
             my.xb[kTaps - 2 + lane + 64 * r] = v;
@@ -117,10 +119,11 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
     __builtin_amdgcn_s_waitcnt(0xC07F);
     const int t = lane;
 #endif
-    for (int b = 0; b < nblk; ++b) {
+    const int bend = b0 + bcount;
+    for (int b = b0; b < bend; ++b) {
         STAMP(0);
         float noff = 0.0f;
-        if (b + 1 < nblk) {
+        if (b + 1 < bend) {
             const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
             noff = osrc ? osrc[b + 1] : 0.0f;
 #pragma unroll
@@ -326,7 +329,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                 my.xa[lane] = keep_x;
                 if (lane >= 1) my.xb[lane - 1] = keep_x;
             }
-            if (b + 1 < nblk) {
+            if (b + 1 < bend) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
                     const float v = osrc ? (pf[r] - noff) : pf[r];        // out[i] - offset (m17_dsp.cpp:217-219)
@@ -347,7 +350,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
     if (lane == 0) {
         cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum; cs.dif = dif;
         cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count;
-        cs.buff[0] = 0.0f;
+        cs.buff[0] = 0.0f; cs.sym_total = sym_total;
         if (counts) counts[chan] = nrec;
     }
     if (lane < kTaps - 1) cs.buff[lane + 1] = my.xa[lane];
