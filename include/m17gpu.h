@@ -108,6 +108,12 @@ int m17gpu_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk,
 int m17gpu_sync_frame(m17gpu_ctx *ctx, const float *d_disc, int nblk,
                       m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts,
                       float *d_syms, int32_t *d_nsyms, void *stream);
+/* Wide-band ingest ahead of the hot path: the Pluto receive decimator,
+ * rx_decimate_filter / sub_filter (radio.cpp:18-40) as run by radio_receive_samples
+ * (:157-177): d_in [C][n_in][2] int16 at 384 kHz -> d_out [C][n_in/8][2] int16 at 48 kHz,
+ * 31-tap symmetric Q15 low-pass, >> 15; the 31-sample history of each channel lives in the
+ * context (zero after m17gpu_reset).  n_in: multiple of 8, >= 32. */
+int m17gpu_pluto_decimate(m17gpu_ctx *ctx, const int16_t *d_in, int n_in, int16_t *d_out, void *stream);
 /* m17_rx_sync_samples alone (m17_rx_sync.cpp:77-99): timing recovery with the lock
  * flag of an EXTERNAL framer (what m17_rx_lock() returns, m17_rx_frame.cpp:187),
  * the same flag for every channel and block of the call.  Framer state untouched. */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "m17gpu_rx_blocks": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "m17gpu_frontend": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "m17gpu_sync_frame": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "m17gpu_pluto_decimate": (_i, [_vp, _vp, _i, _vp, _vp]),
     "m17gpu_sync_samples": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "m17gpu_viterbi_decode": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "m17gpu_demap_frame": (_i, [_vp, _vp, _vp, _i, _vp]),

@@ -99,6 +99,14 @@ class Receiver:
                "m17gpu_sync_frame")
         return out
 
+    def pluto_decimate(self, wide):
+        """wide: int16 cuda tensor [C, n_in, 2] at 384 kHz -> [C, n_in/8, 2] at 48 kHz (radio.cpp:18-40)."""
+        import torch
+        n_in = int(wide.shape[1])
+        out = torch.empty((self.C, n_in // 8, 2), dtype=torch.int16, device=wide.device)
+        _check(lib().m17gpu_pluto_decimate(self._ctx, _ptr(wide), n_in, _ptr(out), _stream()), "m17gpu_pluto_decimate")
+        return out
+
     def viterbi_decode(self, soft):
         import torch
         n, length = int(soft.shape[0]), int(soft.shape[1])

@@ -43,6 +43,7 @@ const Tables &tables();                // built on first use, thread-safe
 
 void build_rrc(float *f, float rolloff, int ntaps, int sps);        // m17_dsp.cpp:295-315
 void set_filter_gain(float *f, float gain, int stride, int ntaps);  // m17_dsp.cpp:420-429
-uint16_t crc16(const uint8_t *p, int n);                            // m17_crc.cpp:26-35
+uint16_t crc16(const uint8_t *p, int n);
+void build_pluto_dec_filter(int16_t *coffs /* [31] */);          // radio.cpp:45-51                            // m17_crc.cpp:26-35
 
 } // namespace m17

@@ -153,6 +153,19 @@ static void build(Tables &T)
     }
 }
 
+// Pluto receive decimator taps (radio.cpp:45-51): rectangular-window low-pass of
+// bandwidth 0.125 (m17_dsp.cpp:347-360), DC gain 0.9, Q15 by truncation (:380-384)
+void build_pluto_dec_filter(int16_t *coffs)
+{
+    float f[31];
+    const double bw = 0.125f;
+    double t = -(31 - 1) / 2;
+    for (int i = 0; i < 31; ++i, t = t + 1.0)
+        f[i] = (float)((t == 0) ? 2.0 * bw : 2.0 * bw * std::sin(M_PI * t * bw) / (M_PI * t * bw));
+    set_filter_gain(f, 0.9f, 1, 31);
+    for (int i = 0; i < 31; ++i) coffs[i] = (int16_t)(f[i] * 0x7FFF);
+}
+
 const Tables &tables()
 {
     static Tables T;

@@ -5,6 +5,7 @@
 #include "m17_sync_wave.hip"
 #include "m17_sync_ch.hip"
 #include "m17_decode_chan.hip"
+#include "m17_pluto.hip"
 #include "m17_host.h"
 #include "../../include/m17gpu.h"
 #include <string>
@@ -28,6 +29,7 @@ struct m17gpu_ctx {
     float *d_disc = nullptr, *d_offs = nullptr, *d_fsym = nullptr;
     int32_t *d_work = nullptr, *d_nwork = nullptr, *d_counts = nullptr;
     uint16_t *d_genc = nullptr, *d_gerr = nullptr, *d_crc_basis = nullptr;
+    uint32_t *d_dec_hist = nullptr;          // [C][32] history of the wide-band decimator
     int decode_impl = 1;                     // 1 = workgroup per channel (decode + bookkeeping), 0 = work list + k_lsf
     bool profiling = false;
     int fe_impl = 0;                         // 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block
@@ -84,6 +86,9 @@ int upload_tables(m17gpu_ctx *ctx)
             msg[i] = (uint8_t)(1u << k);
             basis[i * 8 + k] = (uint16_t)(m17::crc16(msg, 30) ^ 0x1B73);    // remove the init-value term
         }
+    int16_t dec[32] = {0};
+    m17::build_pluto_dec_filter(dec);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dec), dec, sizeof dec));
     HIPCHK(hipMalloc(&ctx->d_crc_basis, sizeof basis));
     HIPCHK(hipMemcpy(ctx->d_crc_basis, basis, sizeof basis, hipMemcpyHostToDevice));
     return M17GPU_OK;
@@ -194,6 +199,7 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     ALLOC(ctx->d_work, sizeof(int32_t) * (size_t)n_channels * ctx->rec_cap_max);
     ALLOC(ctx->d_nwork, sizeof(int32_t) * 4);
     ALLOC(ctx->d_counts, sizeof(int32_t) * (size_t)n_channels);
+    ALLOC(ctx->d_dec_hist, sizeof(uint32_t) * 32 * (size_t)n_channels);
 #undef ALLOC
     rc = m17gpu_reset(ctx, nullptr);
     if (rc != M17GPU_OK) { m17gpu_destroy(ctx); return rc; }
@@ -207,7 +213,7 @@ void m17gpu_destroy(m17gpu_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     void *bufs[] = {ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->d_fsym, ctx->d_work,
-                    ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis};
+                    ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis, ctx->d_dec_hist};
     for (void *p : bufs) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -219,6 +225,7 @@ int m17gpu_reset(m17gpu_ctx *ctx, void *stream)
     const long long words = (long long)ctx->C * (long long)(sizeof(ChanState) / 4);
     hipLaunchKernelGGL(k_reset, dim3(cdiv(words, 256)), dim3(256), 0, S(stream), ctx->d_state, ctx->C);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(ctx->d_dec_hist, 0, sizeof(uint32_t) * 32 * (size_t)ctx->C, S(stream)));
     return M17GPU_OK;
 }
 
@@ -377,6 +384,22 @@ int m17gpu_sync_frame(m17gpu_ctx *ctx, const float *d_disc, int nblk, m17gpu_rec
 {
     if (!ctx || !d_disc || nblk <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_sync_frame: bad argument");
     return launch_sync_frame(ctx, d_disc, nullptr, nblk, 0, d_recs, rec_cap, d_counts, d_syms, d_nsyms, S(stream));
+}
+
+int m17gpu_pluto_decimate(m17gpu_ctx *ctx, const int16_t *d_in, int n_in, int16_t *d_out, void *stream)
+{
+    if (!ctx || !d_in || !d_out || n_in < 32 || (n_in & 7))
+        return fail(M17GPU_ERR_ARG, "m17gpu_pluto_decimate: n_in must be a multiple of 8 and >= 32");
+    hipStream_t st = S(stream);
+    const int M = n_in / 8, wpc = (M + 60) / 61;
+    hipLaunchKernelGGL(k_pluto_decimate, dim3(cdiv((long long)ctx->C * wpc, 4)), dim3(256), 0, st,
+                       reinterpret_cast<const uint32_t *>(d_in), ctx->d_dec_hist,
+                       reinterpret_cast<uint32_t *>(d_out), n_in, wpc);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_pluto_hist, dim3(cdiv((long long)ctx->C * 32, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const uint32_t *>(d_in), ctx->d_dec_hist, n_in, ctx->C);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
 }
 
 int m17gpu_sync_samples(m17gpu_ctx *ctx, const float *d_disc, int nblk, int lock, float *d_syms,

@@ -740,6 +740,58 @@ int m17o_dsp_rx(m17o_chan *st, const int16_t *iq, m17o_rec *recs, int cap, float
     return dsp_rx(st, iq, recs, cap, syms, nsym, 1);
 }
 
+/* ------------------------------------------------------------------ */
+/* Pluto-style wide-band ingest: 384 kHz -> 48 kHz        */
+/* ------------------------------------------------------------------ */
+/* m17_dsp_build_lpf_filter (m17_dsp.cpp:347-360) */
+static void build_lpf(float *filter, float bw, int ntaps)
+{
+    double a, B = bw, t = -(ntaps - 1) / 2;
+    for (int i = 0; i < ntaps; i++) {
+        if (t == 0) a = 2.0 * B;
+        else a = 2.0 * B * sin(M_PI * t * B) / (M_PI * t * B);
+        filter[i] = (float)a;
+        t = t + 1.0;
+    }
+}
+
+/* build_pluto_rx_dec_filter (radio.cpp:45-51): rectangular-window LPF 0.125, DC gain 0.9,
+ * m17_dsp_float_to_short (m17_dsp.cpp:380-384): (int16_t)(f * 0x7FFF), truncating */
+void m17o_pluto_build_dec_filter(int16_t *coffs)
+{
+    float f[31];
+    build_lpf(f, 0.125f, 31);
+    m17o_set_filter_gain(f, 0.9f, 1, 31);
+    for (int i = 0; i < 31; i++) coffs[i] = (int16_t)(f[i] * 0x7FFF);
+}
+
+/* rx_decimate_filter + sub_filter (radio.cpp:18-40) run as radio_receive_samples does
+ * (:157-177): 31-sample history in front of each chunk, output i = taps over buffer[8i..8i+30],
+ * symmetric form, int32 accumulate, arithmetic >> 15, truncation to int16.
+ * hist: 31 complex int16 (zero-initialised static in the reference); n_in multiple of 8, >= 31. */
+void m17o_pluto_decimate(int16_t *hist, const int16_t *in, int n_in, int16_t *out)
+{
+    int16_t c[31];
+    m17o_pluto_build_dec_filter(c);
+    for (int i = 0; i < n_in / 8; i++) {
+        int32_t acc[2];
+        for (int q = 0; q < 2; q++) {
+            /* window sample j is stream sample 8i - 31 + j (negative: history) */
+#define XS(j) (((8 * i - 31 + (j)) < 0) ? hist[2 * (31 + 8 * i - 31 + (j)) + q] : in[2 * (8 * i - 31 + (j)) + q])
+            int32_t real = XS(15) * c[15];
+            for (int k = 0; k < 15; k++) real += c[k] * (XS(k) + XS(30 - k));
+#undef XS
+            acc[q] = real >> 15;
+        }
+        out[2 * i] = (int16_t)acc[0];
+        out[2 * i + 1] = (int16_t)acc[1];
+    }
+    for (int k = 0; k < 31; k++) {
+        hist[2 * k] = in[2 * (n_in - 31 + k)];
+        hist[2 * k + 1] = in[2 * (n_in - 31 + k) + 1];
+    }
+}
+
 int m17o_rx_blocks(m17o_chan *st, int C, int nblk, const int16_t *iq,
                    m17o_rec *recs, int cap, int32_t *counts,
                    float *syms, int32_t *nsyms, int mode, int nthreads)

@@ -138,6 +138,11 @@ int  m17o_rx_blocks(m17o_chan *st, int C, int nblk, const int16_t *iq,
                     float *syms, int32_t *nsyms, int mode, int nthreads);
 int  m17o_sizeof_chan(void);
 
+/* ---- wide-band ingest (radio.cpp:18-51,157-177): 31-tap symmetric /8 decimator, Q15 ---- */
+void m17o_pluto_build_dec_filter(int16_t *coffs /* [31] */);
+void m17o_pluto_decimate(int16_t *hist /* [31][2] state */, const int16_t *in /* [n_in][2] */, int n_in,
+                         int16_t *out /* [n_in/8][2] */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,3 +214,35 @@ def test_empty_and_degenerate_inputs():
     iq[0, 0, 100] = 0
     ref = oracle.Channels(1).rx_blocks(iq, mode=1)
     assert ref["nsyms"][0, 1] in (191, 192, 193)
+
+
+def test_pluto_decimator_oracle_properties():
+    """radio.cpp:18-51,157-177 restated: tap design, DC gain, streaming (chunked == whole)."""
+    L = oracle.L()
+    c = np.zeros(31, np.int16)
+    L.m17o_pluto_build_dec_filter(oracle.vp(c))
+    assert np.array_equal(c, c[::-1]) and c[15] == c.max() and c[7] == 0 and c[23] == 0   # sinc zeros at +-8
+    assert abs(int(c.sum()) - round(0.9 * 32767)) <= 16                                     # truncated Q15, DC gain 0.9
+    rng = np.random.default_rng(4)
+    x = rng.integers(-32768, 32768, (1920 * 8 * 2, 2)).astype(np.int16)
+    whole = np.zeros((len(x) // 8, 2), np.int16)
+    h = np.zeros((31, 2), np.int16)
+    L.m17o_pluto_decimate(oracle.vp(h), oracle.vp(x), len(x), oracle.vp(whole))
+    # the reference consumes 1920 wide-band samples per inner step (radio.cpp:164-172)
+    h2 = np.zeros((31, 2), np.int16)
+    parts = []
+    for k in range(0, len(x), 1920):
+        o = np.zeros((240, 2), np.int16)
+        L.m17o_pluto_decimate(oracle.vp(h2), oracle.vp(np.ascontiguousarray(x[k:k + 1920])), 1920, oracle.vp(o))
+        parts.append(o)
+    np.testing.assert_array_equal(np.concatenate(parts), whole)
+    # direct evaluation of sub_filter on one output
+    i = 777
+    win = x[8 * i - 31: 8 * i].astype(np.int64)
+    want = (win * c[:, None].astype(np.int64)).sum(axis=0) >> 15
+    np.testing.assert_array_equal(whole[i], want.astype(np.int16))
+    # constant input settles at gain sum(c)/32768
+    k = np.full((4000, 2), 10000, np.int16)
+    o = np.zeros((500, 2), np.int16)
+    L.m17o_pluto_decimate(oracle.vp(np.zeros((31, 2), np.int16)), oracle.vp(k), 4000, oracle.vp(o))
+    assert o[-1, 0] == (10000 * int(c.sum())) >> 15
