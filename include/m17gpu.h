@@ -165,6 +165,15 @@ int m17gpu_get_lock(m17gpu_ctx *ctx, uint8_t *h_lock /* [C] */);
 int m17gpu_get_taps(float *h_mf /* [40][31] */, float *h_md /* [40][31] */);
 int m17gpu_get_golay_tables(uint16_t *h_enc /* [4096] */, uint16_t *h_err /* [4096] */);
 
+/* ---------------- output wire format (host) ----------------
+ * The 54-byte M17-over-IP stream frame of the reference's reflector client
+ * (net_add_* m17_net.cpp:25-49, m17_net_new_rx_data :53-74) built from a delivered
+ * record: stream id, the CRC-good LSF (m17gpu_get_lsf row [c][1]), r.fn, &r.data[8].
+ * dst_override: 0 = keep the LSF's destination, else the 48-bit callsign to put there.
+ * Returns 54. */
+int m17gpu_format_net_frame(uint16_t stream_id, const uint8_t lsf[30], uint16_t fn, const uint8_t payload[16],
+                            uint64_t dst_override, uint8_t out[54]);
+
 /* ---------------- synthetic signal source (host) ----------------
  * A restatement of the reference transmitter (framer m17_tx_routines.cpp:24-255,
  * 4-FSK modulator m17_modulate.cpp:22-86, 10 samples/symbol) used to produce

@@ -273,6 +273,27 @@ int m17gen_packet_frame_dibits(const uint8_t *payload, int len, int eof, int nf,
     return 192;
 }
 
+// M17-over-IP stream frame as the reference's reflector client emits it (m17_net.cpp:25-49,
+// 53-74): "M17 " | stream id | LSF bytes 0..27 (no CRC) | FN | 16 payload bytes | CRC-16 of
+// the first 52 bytes.  dst_override != 0 replaces the 6 destination bytes (the reference
+// writes the reflector's own callsign there, m17_net.cpp:60-62).  Unlike the reference
+// (memcpy of 54 bytes from a 30-byte array, :58) nothing is read past lsf[27].
+int m17gpu_format_net_frame(uint16_t stream_id, const uint8_t lsf[30], uint16_t fn, const uint8_t payload[16],
+                            uint64_t dst_override, uint8_t out[54])
+{
+    if (!lsf || !payload || !out) return M17GPU_ERR_ARG;
+    out[0] = 0x4D; out[1] = 0x31; out[2] = 0x37; out[3] = 0x20;
+    out[4] = (uint8_t)(stream_id >> 8); out[5] = (uint8_t)stream_id;
+    std::memcpy(&out[6], lsf, 28);
+    if (dst_override)
+        for (int i = 0; i < 6; ++i) out[6 + i] = (uint8_t)(dst_override >> (40 - 8 * i));
+    out[34] = (uint8_t)(fn >> 8); out[35] = (uint8_t)fn;
+    std::memcpy(&out[36], payload, 16);
+    const uint16_t crc = m17::crc16(out, 52);
+    out[52] = (uint8_t)(crc >> 8); out[53] = (uint8_t)crc;
+    return 54;
+}
+
 static thread_local Modulator g_mod;
 
 int m17gen_modulate(const uint8_t *dibits, int n, int16_t *h_iq, int reset)

@@ -105,3 +105,21 @@ def test_two_rank_scatter_gather_over_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+def test_net_frame_format():
+    """m17_net.cpp:25-74: 54-byte M17-over-IP frame; CRC over the whole frame is zero."""
+    import m17_sdr_amd as m
+    from tests import oracle
+    lib = m.lib()
+    lsf = np.arange(30, dtype=np.uint8)
+    pl = np.arange(100, 116, dtype=np.uint8)
+    out = np.zeros(54, np.uint8)
+    assert lib.m17gpu_format_net_frame(0xBEEF, oracle.vp(lsf), 0x1234, oracle.vp(pl), 0, oracle.vp(out)) == 54
+    assert bytes(out[:4]) == b"M17 " and out[4] == 0xBE and out[5] == 0xEF
+    assert bytes(out[6:34]) == bytes(lsf[:28]) and out[34] == 0x12 and out[35] == 0x34
+    assert bytes(out[36:52]) == bytes(pl)
+    assert oracle.L().m17o_crc(bytes(out), 54) == 0
+    call = lib.m17gen_encode_call(b"M17-M17 A")
+    lib.m17gpu_format_net_frame(1, oracle.vp(lsf), 0, oracle.vp(pl), call, oracle.vp(out))
+    assert int.from_bytes(bytes(out[6:12]), "big") == call and oracle.L().m17o_crc(bytes(out), 54) == 0
