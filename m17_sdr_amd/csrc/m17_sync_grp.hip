@@ -1,0 +1,371 @@
+// m17_sync_grp.hip -- k_sync_frame_grp<LPC>: timing recovery + sync correlator + framer
+// with LPC lanes per channel (64, 32 or 16), i.e. 1, 2 or 4 channels per wave.
+//
+// Reference: m17_rx_sync_samples (m17_rx_sync.cpp:77-99), m17_rx_sym (m17_rx_frame.cpp:126-177).
+//
+// What round-1 profiling showed: one channel's control code -- vote
+// scan, phase stepping, framer -- is ~1,000 scalar-ish instructions per 1920-sample block,
+// and a wave that owns a single channel executes them for one channel's benefit.  Here
+// every control variable is a per-lane value that is equal within a lane GROUP, so one
+// instruction stream drives 64/LPC channels; divergence between the channels of a wave
+// (one hunting, one locked, ...) is ordinary EXEC-mask divergence.  The symbol instants
+// are taken in ROUNDS of LPC consecutive instants: the FIR of a round, the vote ballot of
+// the group, its popcount prefix and threshold test; a crossing ends the round early and
+// the next round starts behind it under the new polyphase branch, so nothing past a
+// crossing is ever evaluated.  The branch taps sit in registers across rounds.
+//
+// LPC is picked from the channel count so that the chip always has >= ~1 wave per SIMD:
+// 64 up to 1,024 channels, 32 up to 2,048, 16 beyond (m17gpu_capi.hip).
+#pragma clang fp contract(off)
+
+namespace m17dev {
+
+struct GrpChan {                           // LDS of one channel
+    float x[kTaps - 1 + kDiscOut + 2];     // delay-line history (30) + this block's 384 inputs
+    float h[8 + 208];                      // m_sync (8) followed by the block's symbols
+    float f[kFrameSyms];                   // m_f_sym
+};
+
+template <int LPC> struct GrpCfg {
+    static constexpr int G = 64 / LPC;                 // channels per wave
+    static constexpr int CPW = 4 * G;                  // channels per 256-thread workgroup
+    static constexpr unsigned long long MASK = (LPC == 64) ? ~0ull : ((1ull << (LPC & 63)) - 1ull);
+};
+
+// m17_sync_check (m17_rx_frame.cpp:47-81) on one 8-symbol vector per lane group; every
+// lane of the group holds v.  Lane k < 6 of the group accumulates template k.
+template <int LPC>
+__device__ __forceinline__ SyncResult sync_check_grp(const float v[8], int gl, int gbase, int gshift)
+{
+    constexpr unsigned negs[6] = {0xAA, 0xB0, 0x4F, 0xF2, 0x0D, 0x40};
+    unsigned neg = negs[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) neg = (gl == k) ? negs[k] : neg;
+    float s = (neg & 1u) ? -v[0] : v[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s = (neg >> i & 1u) ? s - v[i] : s + v[i];
+    float best = 0.0f; int nmax = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float sk = __shfl(s, gbase + k, 64);
+        if (sk > best) { best = sk; nmax = k; }
+    }
+    unsigned nm = negs[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) nm = (nmax == k) ? negs[k] : nm;
+    float mine = v[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mine = (gl == i) ? v[i] : mine;
+    const bool bad = (gl < 8) && ((nm >> gl & 1u) ? (mine > 0.0f) : (mine < 0.0f));
+    const int votes = (int)__popcll((__ballot(bad) >> gshift) & GrpCfg<LPC>::MASK);
+    float mmin = fabsf(v[0]), mmax = mmin;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        const float a = fabsf(v[i]);
+        if (a > mmax) mmax = a;
+        else if (a < mmin) mmin = a;
+    }
+    float var = (mmax - mmin) / mmax;
+    if (var != var) var = 1.0f;
+    SyncResult r; r.type = nmax; r.votes = votes; r.variance = var;
+    return r;
+}
+
+// one record, written by lanes gl < 16 of the group
+__device__ __forceinline__ void emit_record_grp(m17gpu_rec_dev *recs, int rec_cap, int idx, int gl,
+                                                uint32_t w0, uint32_t w1, float var, uint32_t block, uint32_t sympos)
+{
+    if (idx >= rec_cap || gl >= 16) return;
+    uint32_t v = 0;
+    if (gl == 0) v = w0;
+    if (gl == 1) v = w1;
+    if (gl == 2) v = __float_as_uint(var);
+    if (gl == 3) v = block;
+    if (gl == 4) v = sympos;
+    reinterpret_cast<uint32_t *>(&recs[idx])[gl] = v;
+}
+
+template <int LPC>
+__global__ __launch_bounds__(256)
+void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
+                      const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
+                      ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
+                      m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
+                      float *__restrict__ syms, int32_t *__restrict__ nsyms,
+                      float *__restrict__ fsym, int b0, int bcount)
+{
+    using Cfg = GrpCfg<LPC>;
+    __shared__ __attribute__((aligned(16))) float taps[kPhases * 64];      // (matched, derivative) pairs per branch
+    __shared__ __attribute__((aligned(16))) GrpChan chs[Cfg::CPW];
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int grp = lane / LPC, gl = lane % LPC, gbase = lane - gl, gshift = grp * LPC;
+    for (int q = (int)threadIdx.x; q < kPhases * 32; q += 256) {
+        taps[2 * q] = (&c_tab.mf[0][0])[q];
+        taps[2 * q + 1] = (&c_tab.md[0][0])[q];
+    }
+    __syncthreads();                                    // the only workgroup barrier
+    const int chan = ((int)blockIdx.x * 4 + wave) * Cfg::G + grp;
+    if (chan >= C) return;
+    GrpChan &my = chs[wave * Cfg::G + grp];
+    ChanState &cs = st[chan];
+    m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
+    if (!recs) rec_cap = 0;
+    const unsigned long long incl = (gl == 63) ? ~0ull : ((2ull << gl) - 1ull);
+
+    // group-uniform control state, one copy per lane
+    int clk = cs.clk, thr = cs.thr, index = cs.index;
+    float sum = cs.sum, dif = cs.dif;
+    int flock = cs.flock, fclk = cs.fclk, ferr = cs.ferr;
+    uint32_t block_count = cs.block_count;
+    int nrec = (b0 == 0) ? 0 : counts[chan];
+    int sym_total = (b0 == 0) ? 0 : cs.sym_total;
+    for (int q = gl; q < kTaps - 1; q += LPC) my.x[q] = cs.buff[q + 1];
+    if (gl < 8) my.h[gl] = cs.sync[gl];
+    for (int q = gl; q < kFrameSyms; q += LPC) my.f[q] = cs.fsym[q];
+    const size_t sym_base = (size_t)chan * M17_SYM_STRIDE(nblk);
+    const float *dsrc = disc + (size_t)chan * nblk * kDiscOut;
+    const float *osrc = offs ? offs + (size_t)chan * nblk : nullptr;
+    {
+        const float off = osrc ? osrc[b0] : 0.0f;
+        for (int q = gl; q < kDiscOut; q += LPC) {
+            float v = dsrc[(size_t)b0 * kDiscOut + q];
+            if (osrc) v = v - off;                                   // out[i] - offset (m17_dsp.cpp:217-219)
+            my.x[kTaps - 1 + q] = v;
+        }
+    }
+    wave_fence();
+
+    const int bend = b0 + bcount;
+#ifdef M17_STAMPS
+    unsigned long long acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, last_ = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#define GCNT(i) acc_[i] += 1
+#else
+#define GCNT(i) do {} while (0)
+#endif
+    for (int b = b0; b < bend; ++b) {
+        STAMP(5);
+        // ---- timing recovery in rounds of LPC instants; x[i .. i+30] is the delay line at input i
+        const int lockv = (ext_lock >= 0) ? ext_lock : flock;
+        const int thresh = lockv ? 80 : 10;
+        int p = 0, m_idx = 0;
+        {
+            float4 tp[16];                                            // 32 tap pairs of the current branch
+            int tap_index = -1;
+            while (p < kDiscOut) {
+                if (clk == 1) {
+                    GCNT(9);
+                    // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72)
+                    clk = 0;
+                    const float d0 = (sum < 0.0f) ? -dif : dif;
+                    if (d0 > 0.0f) thr++;
+                    if (d0 < 0.0f) thr--;
+                    if (thr > thresh) {
+                        index = (index + 1 == kPhases) ? 0 : index + 1; thr = 0;
+                        if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.h[8 + m_idx] = 0.0f; m_idx++; }
+                    }
+                    if (thr < -thresh) {
+                        thr = 0; index = (index == 0) ? kPhases - 1 : index - 1;
+                        if (index == kPhases - 1) { clk = 1; m_idx--; }
+                    }
+                    p++;
+                    STAMP(0);
+                    continue;
+                }
+                GCNT(8);
+                if (tap_index != index) {
+                    const float4 *t4 = reinterpret_cast<const float4 *>(&taps[64 * index]);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) tp[q] = t4[q];
+                    tap_index = index;
+                }
+                STAMP(0);
+                // one round: lane gl = filter tick at input p + 2 gl and the vote tick after it
+                const int rem = (kDiscOut - p + 1) >> 1;              // filter instants left in the block
+                const int nvalid = rem < LPC ? rem : LPC;
+                const bool have = gl < nvalid;
+                const float *xs = my.x + p + 2 * (have ? gl : 0);
+                float s, d;
+                {
+                    // rx_sync_filter (m17_rx_sync.cpp:25-31), both filters as one packed (s, d) chain
+                    // (p may be odd: plain float reads, the compiler pairs them into ds_read2_b32)
+                    float2 xv[15];
+#pragma unroll
+                    for (int q = 0; q < 15; ++q) { xv[q].x = xs[2 * q]; xv[q].y = xs[2 * q + 1]; }
+                    const float xl = xs[30];
+                    v2f acc = (v2f){xv[0].x, xv[0].x} * (v2f){tp[0].x, tp[0].y};      // bare first product
+                    acc = acc + (v2f){xv[0].y, xv[0].y} * (v2f){tp[0].z, tp[0].w};
+#pragma unroll
+                    for (int q = 1; q < 15; ++q) {
+                        acc = acc + (v2f){xv[q].x, xv[q].x} * (v2f){tp[q].x, tp[q].y};
+                        acc = acc + (v2f){xv[q].y, xv[q].y} * (v2f){tp[q].z, tp[q].w};
+                    }
+                    acc = acc + (v2f){xl, xl} * (v2f){tp[15].x, tp[15].y};
+                    s = acc.x; d = acc.y;
+                }
+                STAMP(1);
+                const bool vote_ok = have && (p + 2 * gl + 1 < kDiscOut);
+                const float dd = (s < 0.0f) ? -d : d;
+                const unsigned long long um = (__ballot(vote_ok && dd > 0.0f) >> gshift) & Cfg::MASK;
+                const unsigned long long dm = (__ballot(vote_ok && dd < 0.0f) >> gshift) & Cfg::MASK;
+                const int tk = thr + (int)__popcll(um & incl) - (int)__popcll(dm & incl);
+                const unsigned long long cr =
+                    (__ballot(vote_ok && (tk > thresh || tk < -thresh)) >> gshift) & Cfg::MASK;
+                const int kl = cr ? (int)__ffsll((long long)cr) - 1 : 0;
+                const int naccept = cr ? kl + 1 : nvalid;
+                if (gl < naccept && (m_idx + gl) >= 0) my.h[8 + m_idx + gl] = s;
+                m_idx += naccept;
+                sum = __shfl(s, gbase + naccept - 1, 64);
+                dif = __shfl(d, gbase + naccept - 1, 64);
+                if (cr) {
+                    const int ts = __shfl(tk, gbase + kl, 64);
+                    thr = 0; clk = 0;
+                    if (ts > thresh) {
+                        index = (index + 1 == kPhases) ? 0 : index + 1;
+                        if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.h[8 + m_idx] = 0.0f; m_idx++; }
+                    } else {
+                        index = (index == 0) ? kPhases - 1 : index - 1;
+                        if (index == kPhases - 1) { clk = 1; m_idx--; }
+                    }
+                    p = p + 2 * kl + 2;
+                } else {
+                    thr += (int)__popcll(um) - (int)__popcll(dm);
+                    const int ilast = p + 2 * (nvalid - 1);
+                    if (ilast + 1 < kDiscOut) { clk = 0; p = ilast + 2; }
+                    else { clk = 1; p = kDiscOut; }
+                }
+                STAMP(2);
+            }
+        }
+        const int n = m_idx > 0 ? m_idx : 0;
+        wave_fence();
+
+        // next block's input: loads issued now, committed after the framer
+        constexpr int PF = kDiscOut / LPC;
+        float pf[PF];
+        float noff = 0.0f;
+        if (b + 1 < bend) {
+            const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
+            noff = osrc ? osrc[b + 1] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < PF; ++r) pf[r] = nx[gl + LPC * r];
+        }
+
+        // symbols out (optional)
+        if (syms) for (int q = gl; q < n; q += LPC) syms[sym_base + sym_total + q] = my.h[8 + q];
+        if (nsyms && gl == 0) nsyms[(size_t)chan * nblk + b] = n;
+        sym_total += n;
+
+        STAMP(3);
+        // ---- framer (m17_rx_frame.cpp:126-177)
+        int pos = (ext_lock >= 0) ? n : 0;
+        while (pos < n) {
+            GCNT(10);
+            if (flock) {
+                const int cnt = min(kFrameSyms - fclk, n - pos);
+                for (int q = gl; q < cnt; q += LPC) my.f[fclk + q] = my.h[8 + pos + q];
+                fclk += cnt; pos += cnt;
+                wave_fence();
+                if (fclk == kFrameSyms) {
+                    fclk = 0;
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = my.f[i];
+                    const SyncResult r = sync_check_grp<LPC>(v, gl, gbase, gshift);
+                    uint32_t flags = 0;
+                    bool parse = false, unlock = false;
+                    if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
+                    else if (sync_accept(r, true)) { flags |= M17_F_SYNC_OK; parse = true; ferr = 0; }
+                    else {
+                        ferr++;
+                        if (ferr > 5) { flags |= M17_F_LOST; unlock = true; }
+                        else parse = true;
+                    }
+                    if (parse && mode == 1) flags |= M17_F_PARSED;
+                    const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
+                    emit_record_grp(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
+                    if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
+                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kFrameSyms;
+                        for (int q = gl; q < kFrameSyms; q += LPC) fd[q] = my.f[q];
+                    }
+                    nrec++;
+                    if (unlock) {
+                        flock = 0;
+                        // reset_sync(): the next hunt windows must see zeros behind them
+                        if (gl < 8) { my.h[pos + gl] = 0.0f; cs.sync[gl] = 0.0f; }
+                        wave_fence();
+                    }
+                }
+            } else {
+                // hunt: candidate j = pos+gl, window = m_sync after shifting symbol j in
+                const int jc = pos + gl;
+                const bool cand = jc < n;
+                const int jj = cand ? jc : pos;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = my.h[jj + 1 + i];
+                unsigned long long hm = 0;
+                SyncResult r; r.type = 0; r.votes = 8; r.variance = 1.0f;
+                if (cand && hunt_compatible(v)) r = sync_check(v);           // most windows are rejected by sign
+                hm = (__ballot(cand && sync_accept(r, false)) >> gshift) & Cfg::MASK;
+                if (hm) {
+                    const int l = (int)__ffsll((long long)hm) - 1;
+                    const int js = pos + l;
+                    // copy_sync(); m_fclk = 8; lock; m17_aos()
+                    float wv = 0.0f;
+                    if (gl < 8) wv = my.h[js + 1 + gl];
+                    wave_fence();
+                    if (gl < 8) { my.f[gl] = wv; cs.sync[gl] = wv; }
+                    fclk = 8; ferr = 0; flock = 1;
+                    const int ty = __shfl(r.type, gbase + l, 64), vo = __shfl(r.votes, gbase + l, 64);
+                    const float va = __shfl(r.variance, gbase + l, 64);
+                    emit_record_grp(crecs, rec_cap, nrec, gl, (uint32_t)ty | ((uint32_t)vo << 8), M17_F_AOS, va,
+                                    block_count, (uint32_t)js);
+                    nrec++;
+                    pos = js + 1;
+                    wave_fence();
+                } else {
+                    pos = min(n, pos + LPC);
+                }
+            }
+        }
+        STAMP(4);
+        // m_sync for the next block while hunting: last 8 entries of h; delay line: last 30
+        // inputs; then the prefetched block moves in
+        {
+            float keep_h = 0.0f;
+            if (gl < 8) keep_h = my.h[n + gl];
+            float keep_x[(kTaps - 1 + LPC - 1) / LPC];
+#pragma unroll
+            for (int r = 0; r < (kTaps - 1 + LPC - 1) / LPC; ++r)
+                keep_x[r] = (gl + LPC * r < kTaps - 1) ? my.x[kDiscOut + gl + LPC * r] : 0.0f;
+            wave_fence();
+            if (!flock && gl < 8) { my.h[gl] = keep_h; cs.sync[gl] = keep_h; }
+#pragma unroll
+            for (int r = 0; r < (kTaps - 1 + LPC - 1) / LPC; ++r)
+                if (gl + LPC * r < kTaps - 1) my.x[gl + LPC * r] = keep_x[r];
+            if (b + 1 < bend) {
+#pragma unroll
+                for (int r = 0; r < PF; ++r)
+                    my.x[kTaps - 1 + gl + LPC * r] = osrc ? (pf[r] - noff) : pf[r];     // out[i] - offset
+            }
+        }
+        block_count++;
+        wave_fence();
+    }
+
+#ifdef M17_STAMPS
+    if (chan == 0 && gl == 0) for (int i = 0; i < 12; ++i) g_stamps[i] = acc_[i];
+#endif
+    // ---- store state
+    if (gl == 0) {
+        cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum; cs.dif = dif;
+        cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count;
+        cs.buff[0] = 0.0f; cs.sym_total = sym_total;
+        if (counts) counts[chan] = nrec;
+    }
+    for (int q = gl; q < kTaps - 1; q += LPC) cs.buff[q + 1] = my.x[q];
+    for (int q = gl; q < kFrameSyms; q += LPC) cs.fsym[q] = my.f[q];
+}
+
+} // namespace m17dev

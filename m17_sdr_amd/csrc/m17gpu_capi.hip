@@ -4,6 +4,7 @@
 #include "m17_sync_wg.hip"
 #include "m17_sync_wave.hip"
 #include "m17_sync_ch.hip"
+#include "m17_sync_grp.hip"
 #include "m17_decode_chan.hip"
 #include "m17_pluto.hip"
 #include "m17_host.h"
@@ -30,10 +31,12 @@ struct m17gpu_ctx {
     int32_t *d_work = nullptr, *d_nwork = nullptr, *d_counts = nullptr;
     uint16_t *d_genc = nullptr, *d_gerr = nullptr, *d_crc_basis = nullptr;
     uint32_t *d_dec_hist = nullptr;          // [C][32] history of the wide-band decimator
+    int lanes_per_channel = 0;               // sync_impl 4: 0 = by channel count, else 16 | 32 | 64
     int decode_impl = 1;                     // 1 = workgroup per channel (decode + bookkeeping), 0 = work list + k_lsf
     bool profiling = false;
     int fe_impl = 0;                         // 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block
-    int sync_impl = 2;                       // 2 = wave per channel (default), 1 = workgroup per channel, 0 = first version
+    int sync_impl = 4;                       // 4 = lane group per channel (default; with decode_impl 0 it runs as 2), 2 = wave per channel,
+                                             // 3 = controller + helper waves, 1 = workgroup per channel, 0 = first version
     int allow_fast = 0;                      // multi-block fast windows in k_sync_frame_wg                       // 1 = workgroup per channel (default), 0 = wave per channel
     std::vector<hipEvent_t> ev_pool;         // 5 events per profiled call
     std::vector<int> ev_mode;                // mode of each profiled call
@@ -127,13 +130,23 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
 {
     if (bcount < 0) bcount = nblk;
     int32_t *wl = ctx->decode_impl == 0 ? ctx->d_work : nullptr;      // the work list exists only for the legacy decode path
-    if (ctx->sync_impl == 3)
+    if (ctx->sync_impl == 4 && ctx->decode_impl == 1) {
+        // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
+        int lpc = ctx->lanes_per_channel;
+        if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
+#define LAUNCH_GRP(L) hipLaunchKernelGGL(k_sync_frame_grp<L>, dim3(cdiv(ctx->C, GrpCfg<L>::CPW)), dim3(256), 0, st, \
+                           disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,                                  \
+                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,                        \
+                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms, ctx->d_fsym, b0, bcount)
+        if (lpc == 64) LAUNCH_GRP(64); else if (lpc == 32) LAUNCH_GRP(32); else LAUNCH_GRP(16);
+#undef LAUNCH_GRP
+    } else if (ctx->sync_impl == 3)
         hipLaunchKernelGGL(k_sync_frame_ch, dim3(ctx->C), dim3(64 * CH_WAVES), 0, st,
                            disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
                            ctx->d_fsym, wl, ctx->d_nwork);
-    else if (ctx->sync_impl == 2)
+    else if (ctx->sync_impl == 2 || ctx->sync_impl == 4)
         hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(ctx->C, SW_WAVES)), dim3(64 * SW_WAVES), 0, st,
                            disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
@@ -183,6 +196,7 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     if (const char *e = std::getenv("M17GPU_FAST_WINDOWS")) ctx->allow_fast = std::atoi(e);
     if (const char *e = std::getenv("M17GPU_FE_IMPL")) ctx->fe_impl = std::atoi(e);
     if (const char *e = std::getenv("M17GPU_SYNC_IMPL")) ctx->sync_impl = std::atoi(e);
+    if (const char *e = std::getenv("M17GPU_LANES_PER_CHANNEL")) ctx->lanes_per_channel = std::atoi(e);
     const size_t cb = (size_t)n_channels * max_blocks;
     int rc = upload_tables(ctx);
     if (rc != M17GPU_OK) { m17gpu_destroy(ctx); return rc; }
@@ -322,7 +336,8 @@ int m17gpu_selftest(m17gpu_ctx *ctx, unsigned *h_bad)
 }
 
 // Implementation selectors, for A/B measurements and so that every kernel variant stays
-// under the parity tests: "sync_impl" 0|1|2, "fast_windows" 0|1, "fe_impl" 0|1|2.
+// under the parity tests: "sync_impl" 0|1|2|3|4, "lanes_per_channel" 0|16|32|64, "fast_windows" 0|1,
+// "fe_impl" 0|1|2, "decode_impl" 0|1.
 int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
@@ -330,6 +345,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "fast_windows")) ctx->allow_fast = value;
     else if (!std::strcmp(name, "fe_impl")) ctx->fe_impl = value;
     else if (!std::strcmp(name, "decode_impl")) ctx->decode_impl = value;
+    else if (!std::strcmp(name, "lanes_per_channel")) ctx->lanes_per_channel = value;
     else return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: unknown option ") + name);
     return M17GPU_OK;
 }

@@ -12,7 +12,7 @@ for _ in range(3): rx.rx_blocks(iq, 0, out)
 torch.cuda.synchronize()
 st = (C.c_ulonglong*16)()
 m.lib().m17gpu_debug_stamps(st)
-names = ["block top (prefetch issue)", "FIR pass (+vote tick)", "scan+decide", "fence", "syms out", "framer", "end-of-block commit"]
-tot = sum(st[:7])
-for i, nme in enumerate(names): print(f"{nme:32s} {st[i]/nblk:9.0f} ticks/block  {100*st[i]/tot:5.1f}%")
-print("total ticks/block", tot/nblk)
+names = ["round top (tap load / vote tick)", "FIR", "vote scan + decide", "fence, prefetch issue, syms out", "framer", "end-of-block commit"]
+tot = sum(st[:6])
+for i, nme in enumerate(names): print(f"{nme:36s} {st[i]/nblk:9.1f} ticks/block  {100*st[i]/tot:5.1f}%")
+print("total ticks/block", tot/nblk, " rounds/block", st[8]/nblk, " lone vote ticks/block", st[9]/nblk, " framer iters/block", st[10]/nblk)
