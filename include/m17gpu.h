@@ -138,8 +138,9 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  * "lanes_per_channel" 0 = by channel count | 16 | 32 | 64 (sync_impl 4);
  * "fast_windows" 0|1 (multi-block windows of sync_impl 1);
  * "fe_impl" 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block;
- * "decode_impl" 1 = workgroup per channel with in-order bookkeeping (default),
- * 0 = work list + separate LSF pass (sync_impl 4 then runs as 2). */
+ * "decode_impl" 2 = per-type work lists, four lanes per frame (DPP-quad Viterbi), wave per
+ * channel for the in-order bookkeeping (default); 1 = workgroup per channel, 16 lanes per
+ * frame; 0 = work list built by the framer + separate LSF pass (sync_impl 4 then runs as 2). */
 int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value);
 
 /* ---------------- measurement hooks ---------------- */

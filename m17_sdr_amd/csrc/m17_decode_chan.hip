@@ -15,11 +15,16 @@
 
 namespace m17dev {
 
-__device__ __forceinline__ uint32_t xor_reduce32(uint32_t v)      // over lanes 0..31 of a wave
+// XOR over lanes 0..31, result wave-uniform.  DPP row operations (quad swaps, half-row and
+// row mirror) instead of ds_bpermute shuffles: this sits on the per-record critical path of
+// the sequential bookkeeping.
+__device__ __forceinline__ uint32_t xor_reduce32(uint32_t v)
 {
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) v ^= (uint32_t)__shfl_xor((int)v, off, 64);
-    return v;
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);    // row_half_mirror
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);    // row_mirror
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
 }
 
 // CRC-16/M17 (m17_crc.cpp:26-35) of 30 bytes held in LDS, computed by lanes 0..29
@@ -28,19 +33,32 @@ __device__ __forceinline__ uint32_t crc30_wave(const uint8_t *p, const uint16_t 
     uint32_t v = 0;
     if (lane < 30) {
         const uint32_t b = p[lane];
+        const uint4 bv = reinterpret_cast<const uint4 *>(basis)[lane];         // the lane's 8 basis words, one LDS read
+        const uint32_t w[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v ^= (b >> k & 1u) ? (uint32_t)basis[lane * 8 + k] : 0u;
+        for (int k = 0; k < 8; ++k) v ^= (b >> k & 1u) ? ((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) : 0u;
     }
     v = xor_reduce32(v);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)(v ^ 0x1B73u));   // 0x1B73 = crc of 30 zero bytes
 }
 
-struct LsfShared {
+struct alignas(16) LsfShared {
     uint16_t basis[240];
     uint16_t crc[256];
     uint8_t  lsf[2][32];
     uint8_t  packet[800];
 };
+
+// channel tables and LICH / packet buffers into LDS, by `nthreads` threads
+__device__ __forceinline__ void lsf_shared_init(LsfShared &ls, const ChanState &cs, const uint16_t *crc_basis, int t, int nthreads)
+{
+    for (int q = t; q < 240; q += nthreads) ls.basis[q] = crc_basis[q];
+    for (int q = t; q < 256; q += nthreads) ls.crc[q] = c_tab.crc[q];
+    for (int q = t; q < 16; q += nthreads) reinterpret_cast<uint32_t *>(ls.lsf)[q] = reinterpret_cast<const uint32_t *>(cs.lsf)[q];
+    for (int q = t; q < 200; q += nthreads) reinterpret_cast<uint32_t *>(ls.packet)[q] = reinterpret_cast<const uint32_t *>(cs.packet)[q];
+}
+
+__device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17gpu_rec_dev *rsrc, int n, LsfShared &ls, int lane);
 
 __global__ __launch_bounds__(256)
 void k_decode_chan(const float *__restrict__ fsym, ChanState *__restrict__ st,
@@ -56,10 +74,7 @@ void k_decode_chan(const float *__restrict__ fsym, ChanState *__restrict__ st,
     m17gpu_rec_dev *crecs = recs + (size_t)chan * rec_cap;
     const int n = min(counts[chan], rec_cap);
 
-    if (t < 240) ls.basis[t] = crc_basis[t];
-    ls.crc[t] = c_tab.crc[t];
-    if (t < 64) reinterpret_cast<uint32_t *>(ls.lsf)[t & 15] = reinterpret_cast<const uint32_t *>(cs.lsf)[t & 15];
-    if (t < 200) reinterpret_cast<uint32_t *>(ls.packet)[t] = reinterpret_cast<const uint32_t *>(cs.packet)[t];
+    lsf_shared_init(ls, cs, crc_basis, t, 256);
 
     // ---- part 1: decode
     DecShared &sh = sh_all[g];
@@ -93,16 +108,23 @@ void k_decode_chan(const float *__restrict__ fsym, ChanState *__restrict__ st,
     }
     __syncthreads();                     // records complete and visible to wave 0 (same CU)
 
-    // ---- part 2: in-order bookkeeping by wave 0, uniform control flow
+    // ---- part 2: in-order bookkeeping by wave 0
     if (t >= 64) return;
-    const int lane = t;
+    bookkeeping_wave(cs, crecs, crecs, n, ls, t);
+}
+
+// What m17_rx_parse does to file-static state, replayed over the channel's records in event
+// order by one wave with uniform control flow (see the file header).  Records are read
+// from rsrc (HBM or an LDS copy); updated flags go to crecs.
+__device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17gpu_rec_dev *rsrc, int n, LsfShared &ls, int lane)
+{
     uint32_t g_errors = (uint32_t)uni((int)cs.g_errors), n_frames = (uint32_t)uni((int)cs.n_frames);
     uint32_t in_frame = (uint32_t)uni((int)cs.in_frame), epoch = (uint32_t)uni((int)cs.frame_id_epoch);
     int packet_idx = uni(cs.packet_idx);
     bool lsf1_ok = crc30_wave(ls.lsf[1], ls.basis, lane) == 0;          // m_lsf[1] only ever changes to CRC-good content
     bool gate_ok = crc30_wave(ls.packet, ls.basis, lane) == 0;           // decode_link_frame's quirk (m17_rx_parse.cpp:98)
     for (int i = 0; i < n; ++i) {
-        const uint32_t *r = reinterpret_cast<const uint32_t *>(&crecs[i]);
+        const uint32_t *r = reinterpret_cast<const uint32_t *>(&rsrc[i]);
         // lanes 0..15 fetch the record words, everything below is wave-uniform
         const uint32_t wv = (lane < 16) ? r[lane] : 0u;
         const uint32_t w0 = (uint32_t)bcast_lane_i((int)wv, 0), w1 = (uint32_t)bcast_lane_i((int)wv, 1);

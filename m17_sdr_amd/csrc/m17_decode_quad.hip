@@ -1,0 +1,344 @@
+// m17_decode_quad.hip -- frame decode with FOUR lanes per frame, four trellis states per
+// lane (included after m17_decode_chan.hip).  decode_impl 2:
+//
+//   k_worklist     one thread per record slot: the decodable frames of all channels are
+//                  appended to one list per frame type (wave-aggregated atomics, ~C*rec_cap/64
+//                  of them -- not one returning atomic per frame inside the sequential framer).
+//   k_decode_quad  one wave per 16 frames.  The add-compare-select butterfly of the K=5 code
+//                  (m17_conv.cpp:73-113) maps onto a DPP quad: lane j holds states 4j..4j+3,
+//                  the predecessors {2v, 2v+1} mod 16 of its four new states sit in quad
+//                  lanes (2j) mod 4 and (2j+1) mod 4, so the eight old metrics arrive as
+//                  quad_perm operands of the eight adds -- no LDS crossbar (ds_bpermute) on
+//                  the per-step critical path, which is what bounds the 16-lane form
+//                  (viterbi16 in m17_kernels.hip).  Soft bits are produced 32 trellis steps
+//                  at a time straight from the frame symbols (demap . de-randomise .
+//                  de-interleave . de-puncture as one table gather), so a frame needs
+//                  1.5 KB of LDS and 16 frames fit a wave.
+//   k_book_chan    the in-order per-channel bookkeeping (part 2 of k_decode_chan), one wave
+//                  per channel.
+//
+// Branch metrics: metric[idx] = (idx&2 ? m1 : -m1) + (idx&1 ? m2 : -m2) (m17_conv.cpp:88-91).
+// Both generators tap the newest and the oldest register bit, so the two predecessors of a
+// state expect complementary dibits: metric[odd] = -metric[even] up to the sign of a zero
+// (IEEE negation commutes with round-to-nearest), and a zero's sign never reaches a
+// comparison: x + (+-0) == x for x != 0, and +0 == -0 under '>'.  Decisions are identical.
+#pragma clang fp contract(off)
+
+namespace m17dev {
+
+constexpr int DQ_FRAMES = 16;                  // frames per wave
+constexpr int DQ_CHUNK  = 32;                  // trellis steps per soft-bit chunk
+constexpr int DQ_RING   = 2 * DQ_CHUNK;
+constexpr int DQ_DECW   = 31;                  // ceil(244 / 8) decision words per lane
+
+struct alignas(16) QuadFrame {                 // 1,552 B = 4 x 97 dwords: the 16 frames of a wave tile all 64 banks
+    float    sym[kFrameSyms];                  // frame symbols
+    uint32_t dec[DQ_DECW][4];                  // decision nibbles: byte [t/2][quad lane], two steps per byte (122 x 4 used)
+    float    ring[DQ_RING];                    // soft bits of the current chunk, (m1, m2) pairs
+    uint8_t  bytes[32];                        // record payload
+};
+static_assert(sizeof(QuadFrame) == 1552, "QuadFrame layout");
+
+template <int CTRL> __device__ __forceinline__ float dppf(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ int dppi(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+// one soft bit of the de-punctured stream from its gather code (-1 = erasure):
+// m17_dsp_demap_symbol (m17_dsp.cpp:35-42) + m17_de_correlate_1 sign
+__device__ __forceinline__ float soft_from_code(int g, const float *sym, float cor)
+{
+    const int s = (g < 0) ? 0 : (g & 0x3FF);
+    const float m = sym[8 + (s >> 1)] * cor;
+    float v = (s & 1) ? (float)((double)fabsf(m) - 0.6666) : -m;
+    if (g & 0x4000) v = -v;
+    return (g < 0) ? 0.0f : v;                  // m17_puncture.cpp:54
+}
+
+// 1,024 threads per workgroup and one atomic per (workgroup, type): all waves appending to
+// the same counter serialise in L2 (measured 40 us for 1,660 wave-level atomics).
+__global__ __launch_bounds__(1024)
+void k_worklist(const m17gpu_rec_dev *__restrict__ recs, int rec_cap, const int32_t *__restrict__ counts, int C,
+                int32_t *__restrict__ work, int32_t *__restrict__ nwork, int cap)
+{
+    __shared__ int wcount[3][16];                 // [type][wave]
+    __shared__ int wbase[3][16];
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int chan = (int)(i / rec_cap), r = (int)(i - (long long)chan * rec_cap);
+    int ty = 0;
+    if (chan < C && r < min(counts[chan], rec_cap)) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&recs[i]);
+        const uint32_t w0 = w[0], w1 = w[1];
+        if ((w1 & M17_F_PARSED) && (w0 & 0xFF) >= 1 && (w0 & 0xFF) <= 3) ty = (int)(w0 & 0xFF);
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned long long m[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        m[k] = __ballot(ty == k + 1);
+        if (lane == 0) wcount[k][wave] = (int)__popcll(m[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = (int)threadIdx.x;
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) { wbase[k][w] = tot; tot += wcount[k][w]; }
+        const int base = tot ? atomicAdd(&nwork[k], tot) : 0;
+        for (int w = 0; w < 16; ++w) wbase[k][w] += base;
+    }
+    __syncthreads();
+    if (ty) work[(size_t)(ty - 1) * cap + wbase[ty - 1][wave] + (int)__popcll(m[ty - 1] & below)] = (int32_t)i;
+}
+
+// One frame type per pass: `type` is wave-uniform (readfirstlane), so trellis length, table row
+// and every loop bound live in SGPRs.  Quads whose frame has another type (plain-batch mode
+// only; the work lists are per type) ride along on their own symbols and write nothing.
+__device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const int16_t *gt, const int16_t *lich, int type, int j, bool writeback, uint32_t r0_keep,
+                                                 m17gpu_rec_dev *rec, const uint32_t (&sgn)[4], const bool (&selA)[4],
+                                                 const uint16_t *genc, const uint16_t *gerr,
+                                                 unsigned long long *acc_, unsigned long long &last_)
+{
+    const int steps = (type == 1) ? 244 : (type == 2 ? 148 : 210);       // DevTables.glen / 2
+    const int nbits = (type == 1) ? 240 : (type == 2 ? 144 : 208);
+    const int boff = (type == 2) ? 6 : 0;
+    // m17_dsp_demap_frame (m17_dsp.cpp:82-95): amplitude reference from the 8 sync symbols
+    float cor;
+    {
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += fabsf(F.sym[i]);
+        cor = 8.0f / sum;                      // (float)(8.0/(double)sum), see limit()
+    }
+    reinterpret_cast<uint2 *>(F.bytes)[j] = make_uint2(0u, 0u);
+    // ---- LICH (m17_rx_parse.cpp:118-135): quad lane j decodes Golay word j
+    uint32_t gerrs = 0;
+    if (type == 2) {
+        uint32_t word = 0;
+        for (int k = 0; k < 24; ++k) {
+            const float v = soft_from_code((int)lich[j * 24 + k], F.sym, cor);
+            word = (word << 1) | (v >= 0.0f ? 1u : 0u);                 // hard_decode_24_bits
+        }
+        int e;
+        const int w = golay_decode(word, genc, gerr, e);
+        const int w0 = dppi<0x00>(w), w1 = dppi<0x55>(w), w2 = dppi<0xAA>(w), w3 = dppi<0xFF>(w);
+        gerrs = (uint32_t)(dppi<0x00>(e) + dppi<0x55>(e) + dppi<0xAA>(e) + dppi<0xFF>(e));
+        group_sync();
+        if (j == 0) {                                                    // pack_12_to_8_x4x6
+            const uint32_t a = ((uint32_t)w0 << 12) | (uint32_t)w1, b = ((uint32_t)w2 << 12) | (uint32_t)w3;
+            F.bytes[0] = (uint8_t)(a >> 16); F.bytes[1] = (uint8_t)(a >> 8); F.bytes[2] = (uint8_t)a;
+            F.bytes[3] = (uint8_t)(b >> 16); F.bytes[4] = (uint8_t)(b >> 8); F.bytes[5] = (uint8_t)b;
+        }
+    }
+    STAMP(1);
+
+    // ---- forward pass (m17_viterbi_decode, m17_conv.cpp:148-158)
+    float acm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acm[i] = (j == 0 && i == 0) ? 1.0f : 0.0f;     // :150-153
+    uint32_t dw = 0;
+    for (int c0 = 0; c0 < steps; c0 += DQ_CHUNK) {
+        // soft bits of steps c0 .. c0+31: quad lane j makes ring[j], ring[j+4], ...
+#pragma unroll 4
+        for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) {
+            const int k = 2 * c0 + j + 4 * r;
+            F.ring[j + 4 * r] = soft_from_code((int)gt[k & 511], F.sym, cor);     // row padded with erasures
+        }
+        group_sync();
+        STAMP(2);
+        const int tend2 = min(DQ_CHUNK, steps - c0) >> 1;     // steps is even
+        const float4 *ring4 = reinterpret_cast<const float4 *>(F.ring);
+        float4 cur = ring4[0];
+        for (int t2 = 0; t2 < tend2; ++t2) {
+            const float4 nxt = ring4[min(t2 + 1, DQ_CHUNK / 2 - 1)];            // one pair ahead: no LDS wait per step
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float m1 = h ? cur.z : cur.x, m2 = h ? cur.w : cur.y;
+                const float a = m1 + m2;                     // metric[3]
+                const float b = m1 + (-m2);                  // metric[2]
+                float nw[4];
+#pragma unroll
+                for (int i = 3; i >= 0; --i) {               // descending: nibble bit i = decision of state 4j+i
+                    const float M = __uint_as_float(__float_as_uint(selA[i] ? a : b) ^ sgn[i]);
+                    // old states 2v, 2v+1 (mod 16): quad lane (2j) mod 4 for i < 2, (2j+1) mod 4 above
+                    float pe, po;
+                    if (i == 0)      { pe = dppf<0x88>(acm[0]); po = dppf<0x88>(acm[1]); }
+                    else if (i == 1) { pe = dppf<0x88>(acm[2]); po = dppf<0x88>(acm[3]); }
+                    else if (i == 2) { pe = dppf<0xDD>(acm[0]); po = dppf<0xDD>(acm[1]); }
+                    else             { pe = dppf<0xDD>(acm[2]); po = dppf<0xDD>(acm[3]); }
+                    const float ta = pe + M, tb = po - M;
+                    const bool odd = !(ta > tb);             // strict '>' : ties pick the odd predecessor
+                    nw[i] = odd ? tb : ta;
+                    dw = (dw << 1) | (odd ? 1u : 0u);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acm[i] = nw[i];
+            }
+            // two steps per byte: even step in the high nibble
+            reinterpret_cast<uint8_t *>(F.dec)[4 * ((c0 >> 1) + t2) + j] = (uint8_t)dw;
+            cur = nxt;
+        }
+        group_sync();
+        STAMP(3);
+    }
+
+    // ---- traceback from state 0 (:160-166) and pack_1_to_8(&bits[1], ...) in one go.
+    // dword t/2 of dec holds the four lanes' bytes: decision of state s at step t is bit
+    // 8 (s >> 2) + (s & 3) + (t even ? 4 : 0).
+    {
+        int state = 0;
+        uint32_t acc = 0;
+        const uint4 *dq = reinterpret_cast<const uint4 *>(F.dec);
+        for (int g = (steps - 1) >> 3; g >= 0; --g) {
+            const uint4 W = dq[g];                         // steps 8g .. 8g+7, one LDS read
+#pragma unroll
+            for (int tt = 7; tt >= 0; --tt) {
+                const int t = 8 * g + tt;
+                if (t < steps) {                           // scalar: only the top group is partial
+                    const uint32_t wv = (tt >> 1) == 0 ? W.x : ((tt >> 1) == 1 ? W.y : ((tt >> 1) == 2 ? W.z : W.w));
+                    const int pos = (((state & 12) << 1) | (state & 3)) + ((tt & 1) ? 0 : 4);
+                    const int d = (int)((wv >> pos) & 1u);
+                    state = ((state << 1) & 15) | d;
+                    const int u = t - 1;                   // bits[t] -> output bit u
+                    if (u >= 0 && u < nbits) acc |= (uint32_t)(state >> 3) << ((u & 31) ^ 7);
+                }
+                // after u = 8g (tt == 1) output word g/4 is complete when 8g is a multiple of 32
+                if (tt == 1 && (g & 3) == 0 && 8 * g < nbits) {
+                    if (j == 0) {
+                        uint16_t *o = reinterpret_cast<uint16_t *>(F.bytes + boff + 4 * (g >> 2));
+                        o[0] = (uint16_t)acc; o[1] = (uint16_t)(acc >> 16);
+                    }
+                    acc = 0;
+                }
+            }
+        }
+    }
+    group_sync();
+    STAMP(4);
+    uint32_t fn = 0;
+    if (type == 2) fn = ((uint32_t)F.bytes[6] << 8) | F.bytes[7];                     // pack_8_to_16
+    if (type == 3) fn = ((uint32_t)(F.bytes[25] >> 7) << 8) | ((F.bytes[25] >> 2) & 0x1F);
+    if (writeback) {
+        uint32_t *r = reinterpret_cast<uint32_t *>(rec);
+        const uint32_t *bw = reinterpret_cast<const uint32_t *>(F.bytes);
+        r[5 + j] = bw[j]; r[9 + j] = bw[4 + j];
+        if (j == 0) {
+            r[0] = (r0_keep & 0xFF00FFFFu) | ((gerrs & 0xFF) << 16);
+            r[1] = (r[1] & 0x0000FFFFu) | (fn << 16);
+        }
+    }
+    group_sync();
+}
+
+// work != nullptr: lists per type (work[3][cap], nwork[3]); else plain batch: frame i of
+// n_plain, type from types[i], record i
+__global__ __launch_bounds__(64)
+void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ work,
+                   const int32_t *__restrict__ nwork, int cap,
+                   const uint8_t *__restrict__ types, int n_plain,
+                   m17gpu_rec_dev *__restrict__ recs,
+                   const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr)
+{
+    __shared__ __attribute__((aligned(16))) QuadFrame fr[DQ_FRAMES];        // 24.8 KB (+1.2 KB tables): six waves per CU
+    __shared__ int16_t gt_row[512];                                         // DevTables.gather row of the current type
+    __shared__ int16_t lich_row[96];
+    const int lane = lane_id(), q = lane >> 2, j = lane & 3;
+    QuadFrame &F = fr[q];
+
+    // per-lane constants of the butterfly: state v = 4j+i, even predecessor's metric index
+    uint32_t sgn[4]; bool selA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = c_tab.bm_even[4 * j + i];
+        selA[i] = (idx == 0 || idx == 3);         // +-(m1 + m2), else +-(m1 - m2)
+        sgn[i] = (idx < 2) ? 0x80000000u : 0u;
+    }
+
+    for (int i = lane; i < 96; i += 64) lich_row[i] = c_tab.lich[i];
+    int row_type = 0;
+    int n1 = 0, n2 = 0, n3 = 0;
+    if (work) { n1 = nwork[0]; n2 = nwork[1]; n3 = nwork[2]; }
+    const int t2 = (n2 + DQ_FRAMES - 1) / DQ_FRAMES, t1 = (n1 + DQ_FRAMES - 1) / DQ_FRAMES,
+              t3 = (n3 + DQ_FRAMES - 1) / DQ_FRAMES;
+    const int ntask = uni(work ? (t2 + t1 + t3) : (n_plain + DQ_FRAMES - 1) / DQ_FRAMES);
+
+    unsigned long long acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, last_ = 0;
+#ifdef M17_STAMPS
+    last_ = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    for (int task = (int)blockIdx.x; task < ntask; task += (int)gridDim.x) {
+        STAMP(6);
+        // ---- which frame
+        int qtype, slot; bool active;
+        if (work) {
+            int seg, base, n;
+            if (task < t2) { seg = 1; base = task * DQ_FRAMES; n = n2; }                    // stream frames first
+            else if (task < t2 + t1) { seg = 0; base = (task - t2) * DQ_FRAMES; n = n1; }
+            else { seg = 2; base = (task - t2 - t1) * DQ_FRAMES; n = n3; }
+            active = base + q < n;
+            slot = work[(size_t)seg * cap + (active ? base + q : n - 1)];
+            qtype = seg + 1;
+        } else {
+            const int item = task * DQ_FRAMES + q;
+            active = item < n_plain;
+            slot = active ? item : n_plain - 1;
+            qtype = (int)types[slot];
+        }
+        // ---- symbols in
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(fsym + (size_t)slot * kFrameSyms);
+            float4 *dst = reinterpret_cast<float4 *>(F.sym);
+#pragma unroll
+            for (int r = 0; r < 12; ++r) dst[j + 4 * r] = src[j + 4 * r];
+        }
+        m17gpu_rec_dev *rec = &recs[slot];
+        const uint32_t r0_keep = work ? reinterpret_cast<const uint32_t *>(rec)[0] : (uint32_t)qtype;
+        group_sync();
+        STAMP(0);
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+            const int type = (pass == 0) ? 2 : (pass == 1 ? 1 : 3);
+            if (__ballot(qtype == type) == 0ull) continue;
+            if (row_type != type) {
+                for (int i = lane; i < 512; i += 64) gt_row[i] = (i < 488) ? c_tab.gather[type][i] : (int16_t)-1;
+                row_type = type;
+                group_sync();
+            }
+            decode_quad_pass(F, gt_row, lich_row, type, j, active && qtype == type, r0_keep, rec, sgn, selA, genc, gerr, acc_, last_);
+        }
+        STAMP(5);
+    }
+#ifdef M17_STAMPS
+    if (blockIdx.x == 0 && lane == 0) { for (int i = 0; i < 7; ++i) g_stamps[i] = acc_[i]; g_stamps[8] = (unsigned long long)ntask; }
+#endif
+}
+
+// the in-order bookkeeping of k_decode_chan as its own kernel: one wave per channel.  The
+// channel's records are staged in LDS first -- read one by one from HBM the 51 dependent
+// loads alone cost 50 us.
+__global__ __launch_bounds__(64)
+void k_book_chan(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs, int rec_cap,
+                 const int32_t *__restrict__ counts, const uint16_t *__restrict__ crc_basis, int staged)
+{
+    __shared__ LsfShared ls;
+    extern __shared__ __attribute__((aligned(16))) uint32_t rec_stage[];      // [rec_cap][16] dwords
+    const int lane = lane_id(), chan = (int)blockIdx.x;
+    ChanState &cs = st[chan];
+    m17gpu_rec_dev *crecs = recs + (size_t)chan * rec_cap;
+    const int n = min(counts[chan], rec_cap);
+    if (staged) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(crecs);
+        uint4 *dst = reinterpret_cast<uint4 *>(rec_stage);
+        for (int q = lane; q < n * 4; q += 64) dst[q] = src[q];
+    }
+    lsf_shared_init(ls, cs, crc_basis, lane, 64);
+    group_sync();
+    bookkeeping_wave(cs, crecs, staged ? reinterpret_cast<const m17gpu_rec_dev *>(rec_stage) : crecs, n, ls, lane);
+}
+
+} // namespace m17dev

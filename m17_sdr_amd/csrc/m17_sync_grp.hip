@@ -85,6 +85,82 @@ __device__ __forceinline__ void emit_record_grp(m17gpu_rec_dev *recs, int rec_ca
     reinterpret_cast<uint32_t *>(&recs[idx])[gl] = v;
 }
 
+// rx_sync_filter (m17_rx_sync.cpp:25-31): matched and derivative filter as one packed (s, d)
+// chain, ascending order, bare first product.  xs = delay line at this instant, tp = 32 tap pairs.
+__device__ __forceinline__ v2f fir_pair(const float *xs, const float4 (&tp)[16])
+{
+    // (the offset may be odd: plain float reads, the compiler pairs them into ds_read2_b32)
+    float2 xv[15];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) { xv[q].x = xs[2 * q]; xv[q].y = xs[2 * q + 1]; }
+    const float xl = xs[30];
+    v2f acc = (v2f){xv[0].x, xv[0].x} * (v2f){tp[0].x, tp[0].y};
+    acc = acc + (v2f){xv[0].y, xv[0].y} * (v2f){tp[0].z, tp[0].w};
+#pragma unroll
+    for (int q = 1; q < 15; ++q) {
+        acc = acc + (v2f){xv[q].x, xv[q].x} * (v2f){tp[q].x, tp[q].y};
+        acc = acc + (v2f){xv[q].y, xv[q].y} * (v2f){tp[q].z, tp[q].w};
+    }
+    return acc + (v2f){xl, xl} * (v2f){tp[15].x, tp[15].y};
+}
+
+// One pass of the timing loop over up to W*LPC instants starting at input p (clk == 0 on
+// entry): W independent FIR chains per lane, then the vote ticks in time order (sync_update
+// m17_rx_sync.cpp:38-42, m17_sync_adjust :45-72).  The first threshold crossing ends the pass.
+template <int LPC, int W>
+__device__ __forceinline__ void timing_pass(GrpChan &my, const float4 (&tp)[16], int gl, int gbase, int gshift,
+                                            unsigned long long incl, int thresh, int rem, int &p, int &m_idx,
+                                            int &clk, int &thr, int &index, float &sum, float &dif)
+{
+    using Cfg = GrpCfg<LPC>;
+    float s[W], d[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const int inst = gl + LPC * j;
+        const v2f a = fir_pair(my.x + p + 2 * (inst < rem ? inst : 0), tp);
+        s[j] = a.x; d[j] = a.y;
+    }
+    bool crossed = false;
+    int ts = 0, kcross = 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const int nv = min(rem - LPC * j, LPC);                     // valid instants of this segment
+        if (!crossed && nv > 0) {
+            const int inst = gl + LPC * j;
+            const bool vote_ok = (gl < nv) && (p + 2 * inst + 1 < kDiscOut);
+            const float dd = (s[j] < 0.0f) ? -d[j] : d[j];
+            const unsigned long long um = (__ballot(vote_ok && dd > 0.0f) >> gshift) & Cfg::MASK;
+            const unsigned long long dm = (__ballot(vote_ok && dd < 0.0f) >> gshift) & Cfg::MASK;
+            const int tk = thr + (int)__popcll(um & incl) - (int)__popcll(dm & incl);
+            const unsigned long long cr =
+                (__ballot(vote_ok && (tk > thresh || tk < -thresh)) >> gshift) & Cfg::MASK;
+            const int kl = cr ? (int)__ffsll((long long)cr) - 1 : 0;
+            const int naccept = cr ? kl + 1 : nv;
+            if (gl < naccept && (m_idx + gl) >= 0) my.h[8 + m_idx + gl] = s[j];
+            m_idx += naccept;
+            sum = __shfl(s[j], gbase + naccept - 1, 64);
+            dif = __shfl(d[j], gbase + naccept - 1, 64);
+            if (cr) { crossed = true; ts = __shfl(tk, gbase + kl, 64); kcross = LPC * j + kl; }
+            else thr += (int)__popcll(um) - (int)__popcll(dm);
+        }
+    }
+    if (crossed) {
+        thr = 0; clk = 0;
+        if (ts > thresh) {
+            index = (index + 1 == kPhases) ? 0 : index + 1;
+            if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.h[8 + m_idx] = 0.0f; m_idx++; }
+        } else {
+            index = (index == 0) ? kPhases - 1 : index - 1;
+            if (index == kPhases - 1) { clk = 1; m_idx--; }
+        }
+        p = p + 2 * kcross + 2;
+    } else {
+        const int ilast = p + 2 * (min(rem, W * LPC) - 1);
+        if (ilast + 1 < kDiscOut) { clk = 0; p = ilast + 2; }
+        else { clk = 1; p = kDiscOut; }
+    }
+}
+
 template <int LPC>
 __global__ __launch_bounds__(256)
 void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
@@ -180,60 +256,13 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
                     tap_index = index;
                 }
                 STAMP(0);
-                // one round: lane gl = filter tick at input p + 2 gl and the vote tick after it
+                // one pass: lane gl takes the filter ticks at inputs p + 2 (gl + LPC j), j < W, and the vote
+                // ticks after them.  W = 3 covers a whole block when the loop is locked (threshold 80: a
+                // crossing, which voids the rest of the pass, comes about every second block); while
+                // hunting (threshold 10) crossings are frequent and a pass is one round of LPC instants.
                 const int rem = (kDiscOut - p + 1) >> 1;              // filter instants left in the block
-                const int nvalid = rem < LPC ? rem : LPC;
-                const bool have = gl < nvalid;
-                const float *xs = my.x + p + 2 * (have ? gl : 0);
-                float s, d;
-                {
-                    // rx_sync_filter (m17_rx_sync.cpp:25-31), both filters as one packed (s, d) chain
-                    // (p may be odd: plain float reads, the compiler pairs them into ds_read2_b32)
-                    float2 xv[15];
-#pragma unroll
-                    for (int q = 0; q < 15; ++q) { xv[q].x = xs[2 * q]; xv[q].y = xs[2 * q + 1]; }
-                    const float xl = xs[30];
-                    v2f acc = (v2f){xv[0].x, xv[0].x} * (v2f){tp[0].x, tp[0].y};      // bare first product
-                    acc = acc + (v2f){xv[0].y, xv[0].y} * (v2f){tp[0].z, tp[0].w};
-#pragma unroll
-                    for (int q = 1; q < 15; ++q) {
-                        acc = acc + (v2f){xv[q].x, xv[q].x} * (v2f){tp[q].x, tp[q].y};
-                        acc = acc + (v2f){xv[q].y, xv[q].y} * (v2f){tp[q].z, tp[q].w};
-                    }
-                    acc = acc + (v2f){xl, xl} * (v2f){tp[15].x, tp[15].y};
-                    s = acc.x; d = acc.y;
-                }
-                STAMP(1);
-                const bool vote_ok = have && (p + 2 * gl + 1 < kDiscOut);
-                const float dd = (s < 0.0f) ? -d : d;
-                const unsigned long long um = (__ballot(vote_ok && dd > 0.0f) >> gshift) & Cfg::MASK;
-                const unsigned long long dm = (__ballot(vote_ok && dd < 0.0f) >> gshift) & Cfg::MASK;
-                const int tk = thr + (int)__popcll(um & incl) - (int)__popcll(dm & incl);
-                const unsigned long long cr =
-                    (__ballot(vote_ok && (tk > thresh || tk < -thresh)) >> gshift) & Cfg::MASK;
-                const int kl = cr ? (int)__ffsll((long long)cr) - 1 : 0;
-                const int naccept = cr ? kl + 1 : nvalid;
-                if (gl < naccept && (m_idx + gl) >= 0) my.h[8 + m_idx + gl] = s;
-                m_idx += naccept;
-                sum = __shfl(s, gbase + naccept - 1, 64);
-                dif = __shfl(d, gbase + naccept - 1, 64);
-                if (cr) {
-                    const int ts = __shfl(tk, gbase + kl, 64);
-                    thr = 0; clk = 0;
-                    if (ts > thresh) {
-                        index = (index + 1 == kPhases) ? 0 : index + 1;
-                        if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.h[8 + m_idx] = 0.0f; m_idx++; }
-                    } else {
-                        index = (index == 0) ? kPhases - 1 : index - 1;
-                        if (index == kPhases - 1) { clk = 1; m_idx--; }
-                    }
-                    p = p + 2 * kl + 2;
-                } else {
-                    thr += (int)__popcll(um) - (int)__popcll(dm);
-                    const int ilast = p + 2 * (nvalid - 1);
-                    if (ilast + 1 < kDiscOut) { clk = 0; p = ilast + 2; }
-                    else { clk = 1; p = kDiscOut; }
-                }
+                if (lockv) timing_pass<LPC, 3>(my, tp, gl, gbase, gshift, incl, thresh, rem, p, m_idx, clk, thr, index, sum, dif);
+                else       timing_pass<LPC, 1>(my, tp, gl, gbase, gshift, incl, thresh, rem, p, m_idx, clk, thr, index, sum, dif);
                 STAMP(2);
             }
         }

@@ -6,6 +6,7 @@
 #include "m17_sync_ch.hip"
 #include "m17_sync_grp.hip"
 #include "m17_decode_chan.hip"
+#include "m17_decode_quad.hip"
 #include "m17_pluto.hip"
 #include "m17_host.h"
 #include "../../include/m17gpu.h"
@@ -32,7 +33,8 @@ struct m17gpu_ctx {
     uint16_t *d_genc = nullptr, *d_gerr = nullptr, *d_crc_basis = nullptr;
     uint32_t *d_dec_hist = nullptr;          // [C][32] history of the wide-band decimator
     int lanes_per_channel = 0;               // sync_impl 4: 0 = by channel count, else 16 | 32 | 64
-    int decode_impl = 1;                     // 1 = workgroup per channel (decode + bookkeeping), 0 = work list + k_lsf
+    int decode_impl = 2;                     // 2 = per-type work lists + four lanes per frame + wave-per-channel bookkeeping (default),
+                                             // 1 = workgroup per channel (16 lanes per frame + bookkeeping), 0 = work list built by the framer + k_lsf
     bool profiling = false;
     int fe_impl = 0;                         // 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block
     int sync_impl = 4;                       // 4 = lane group per channel (default; with decode_impl 0 it runs as 2), 2 = wave per channel,
@@ -130,7 +132,7 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
 {
     if (bcount < 0) bcount = nblk;
     int32_t *wl = ctx->decode_impl == 0 ? ctx->d_work : nullptr;      // the work list exists only for the legacy decode path
-    if (ctx->sync_impl == 4 && ctx->decode_impl == 1) {
+    if (ctx->sync_impl == 4 && ctx->decode_impl != 0) {
         // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
         int lpc = ctx->lanes_per_channel;
         if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
@@ -196,6 +198,7 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     if (const char *e = std::getenv("M17GPU_FAST_WINDOWS")) ctx->allow_fast = std::atoi(e);
     if (const char *e = std::getenv("M17GPU_FE_IMPL")) ctx->fe_impl = std::atoi(e);
     if (const char *e = std::getenv("M17GPU_SYNC_IMPL")) ctx->sync_impl = std::atoi(e);
+    if (const char *e = std::getenv("M17GPU_DECODE_IMPL")) ctx->decode_impl = std::atoi(e);
     if (const char *e = std::getenv("M17GPU_LANES_PER_CHANNEL")) ctx->lanes_per_channel = std::atoi(e);
     const size_t cb = (size_t)n_channels * max_blocks;
     int rc = upload_tables(ctx);
@@ -210,7 +213,7 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     ALLOC(ctx->d_disc, sizeof(float) * cb * kDiscOut);
     ALLOC(ctx->d_offs, sizeof(float) * cb);
     ALLOC(ctx->d_fsym, sizeof(float) * (size_t)n_channels * ctx->rec_cap_max * kFrameSyms);
-    ALLOC(ctx->d_work, sizeof(int32_t) * (size_t)n_channels * ctx->rec_cap_max);
+    ALLOC(ctx->d_work, sizeof(int32_t) * 3 * (size_t)n_channels * ctx->rec_cap_max);   // one list per frame type (decode_impl 2)
     ALLOC(ctx->d_nwork, sizeof(int32_t) * 4);
     ALLOC(ctx->d_counts, sizeof(int32_t) * (size_t)n_channels);
     ALLOC(ctx->d_dec_hist, sizeof(uint32_t) * 32 * (size_t)n_channels);
@@ -253,7 +256,7 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
         return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: mode 1 needs d_recs and 0 < rec_cap <= 2*max_blocks+2");
     hipStream_t st = S(stream);
     int rc;
-    if ((mode & 0xFF) == 1) HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t), st));
+    if ((mode & 0xFF) == 1) HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t) * 4, st));
     hipEvent_t *ev = nullptr;
     if (ctx->profiling && ctx->ev_mode.size() < 512) {
         const size_t base = ctx->ev_pool.size();
@@ -277,7 +280,24 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
     MARK(2);
     if ((mode & 0xFF) == 1) {
         int32_t *cnt = d_counts ? d_counts : ctx->d_counts;
-        if (ctx->decode_impl == 1) {
+        if (ctx->decode_impl == 2) {
+            const long long slots = (long long)ctx->C * rec_cap;
+            hipLaunchKernelGGL(k_worklist, dim3(cdiv(slots, 1024)), dim3(1024), 0, st,
+                               reinterpret_cast<const m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->C,
+                               ctx->d_work, ctx->d_nwork, (int)slots);
+            int grid = cdiv(slots, DQ_FRAMES) + 3;
+            if (grid > 256 * 6) grid = 256 * 6;                      // 6 single-wave workgroups per CU by LDS
+            hipLaunchKernelGGL(k_decode_quad, dim3(grid), dim3(64), 0, st, ctx->d_fsym, ctx->d_work, ctx->d_nwork,
+                               (int)slots, (const uint8_t *)nullptr, 0, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
+                               ctx->d_genc, ctx->d_gerr);
+            HIPCHK(hipGetLastError());
+            MARK(3);
+            const int staged = (size_t)rec_cap * 64 <= 48 * 1024;         // records of one channel in LDS
+            hipLaunchKernelGGL(k_book_chan, dim3(ctx->C), dim3(64), staged ? (size_t)rec_cap * 64 : 0, st, ctx->d_state,
+                               reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->d_crc_basis, staged);
+            HIPCHK(hipGetLastError());
+            MARK(4);
+        } else if (ctx->decode_impl == 1) {
             hipLaunchKernelGGL(k_decode_chan, dim3(ctx->C), dim3(256), 0, st, ctx->d_fsym, ctx->d_state,
                                reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->d_genc, ctx->d_gerr,
                                ctx->d_crc_basis);
@@ -322,12 +342,11 @@ int m17gpu_selftest(m17gpu_ctx *ctx, unsigned *h_bad)
     HIPCHK(hipMalloc(&d_bad, 4 * sizeof(unsigned)));
     HIPCHK(hipMemset(d_bad, 0, 4 * sizeof(unsigned)));
     hipLaunchKernelGGL(k_selftest_scale, dim3(256), dim3(256), 0, nullptr, d_bad + 0);
-    // a = re^2 + im^2 lies in [9e-10, 2]; sweep every float in [2^-32, 8) and zero
+    // a = re^2 + im^2 lies in [9e-10, 2]; sweep every float in [2^-32, 8)
     hipLaunchKernelGGL(k_selftest_sqrt, dim3(4096), dim3(256), 0, nullptr, 0x2F800000u, 0x41000000u, d_bad + 1);
-    hipLaunchKernelGGL(k_selftest_sqrt, dim3(1), dim3(64), 0, nullptr, 0u, 0u, d_bad + 1);
     // m = sqrt(a) lies in [3e-5, 1.42]; sweep every float in [2^-17, 4)
     hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(256), 0, nullptr, 0x37000000u, 0x40800000u, d_bad + 2);
-    hipLaunchKernelGGL(k_selftest_limit, dim3(((1u << 24) + (1u << 26)) / 256), dim3(256), 0, nullptr, d_bad + 3);
+    hipLaunchKernelGGL(k_selftest_limit, dim3(8192), dim3(256), 0, nullptr, d_bad + 3);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(h_bad, d_bad, 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -337,7 +356,7 @@ int m17gpu_selftest(m17gpu_ctx *ctx, unsigned *h_bad)
 
 // Implementation selectors, for A/B measurements and so that every kernel variant stays
 // under the parity tests: "sync_impl" 0|1|2|3|4, "lanes_per_channel" 0|16|32|64, "fast_windows" 0|1,
-// "fe_impl" 0|1|2, "decode_impl" 0|1.
+// "fe_impl" 0|1|2, "decode_impl" 0|1|2.
 int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
@@ -448,11 +467,19 @@ int m17gpu_decode_frames(m17gpu_ctx *ctx, const float *d_sym, const uint8_t *d_t
     if (!ctx || !d_sym || !d_type || !d_recs || n <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_decode_frames: bad argument");
     hipStream_t st = S(stream);
     HIPCHK(hipMemsetAsync(d_recs, 0, sizeof(m17gpu_rec) * (size_t)n, st));
-    int grid = cdiv(n, DEC_FRAMES_PER_WG);
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_decode, dim3(grid), dim3(256), 0, st, d_sym, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr, n, d_type, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
-                       ctx->d_genc, ctx->d_gerr);
+    if (ctx->decode_impl == 2) {
+        int grid = cdiv(n, DQ_FRAMES);
+        if (grid > 256 * 6) grid = 256 * 6;
+        hipLaunchKernelGGL(k_decode_quad, dim3(grid), dim3(64), 0, st, d_sym, (const int32_t *)nullptr,
+                           (const int32_t *)nullptr, 0, d_type, n, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
+                           ctx->d_genc, ctx->d_gerr);
+    } else {
+        int grid = cdiv(n, DEC_FRAMES_PER_WG);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(k_decode, dim3(grid), dim3(256), 0, st, d_sym, (const int32_t *)nullptr,
+                           (const int32_t *)nullptr, n, d_type, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
+                           ctx->d_genc, ctx->d_gerr);
+    }
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
