@@ -256,13 +256,12 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
                     tap_index = index;
                 }
                 STAMP(0);
-                // one pass: lane gl takes the filter ticks at inputs p + 2 (gl + LPC j), j < W, and the vote
-                // ticks after them.  W = 3 covers a whole block when the loop is locked (threshold 80: a
-                // crossing, which voids the rest of the pass, comes about every second block); while
-                // hunting (threshold 10) crossings are frequent and a pass is one round of LPC instants.
+                // one pass = one round: lane gl takes the filter tick at input p + 2 gl and the vote tick
+                // after it.  (Passes of three rounds with three FIR chains per lane were measured while
+                // locked: same time at 64 lanes per channel -- a lone wave is issue-bound, not latency-
+                // bound -- and 15% slower at 32 / 16 lanes from the extra registers.  W stays 1.)
                 const int rem = (kDiscOut - p + 1) >> 1;              // filter instants left in the block
-                if (lockv) timing_pass<LPC, 3>(my, tp, gl, gbase, gshift, incl, thresh, rem, p, m_idx, clk, thr, index, sum, dif);
-                else       timing_pass<LPC, 1>(my, tp, gl, gbase, gshift, incl, thresh, rem, p, m_idx, clk, thr, index, sum, dif);
+                timing_pass<LPC, 1>(my, tp, gl, gbase, gshift, incl, thresh, rem, p, m_idx, clk, thr, index, sum, dif);
                 STAMP(2);
             }
         }
