@@ -146,7 +146,7 @@ def main():
     msym = syms / dt / 1e6
     cb_per_launch = C * nblk
     per_unit = BYTES_FRONT if mode == 0 else BYTES_FULL
-    names = ["k_frontend", "k_sync_frame", "k_decode+bookkeeping", "k_lsf"]
+    names = ["k_frontend", "k_sync_frame", "k_worklist+k_decode", "k_bookkeeping"]
     used = [i for i in range(4) if kms[i] > 0.002]
     t_path_ms = sum(kms[i] for i in used)
     dom = max(used, key=lambda i: kms[i]) if used else 0

@@ -147,7 +147,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value);
 /* When on, m17gpu_rx_blocks brackets each of its kernels with HIP events on the
  * launch stream (up to 512 calls are kept).  m17gpu_get_kernel_ms waits for the
  * recorded events and returns the average milliseconds per launch of
- * {k_frontend, k_sync_frame, k_decode, k_lsf} and the number of calls averaged,
+ * {k_frontend, k_sync_frame, k_worklist + k_decode, k_bookkeeping} and the number of calls averaged,
  * then clears the record. */
 int m17gpu_set_profiling(m17gpu_ctx *ctx, int on);
 int m17gpu_get_kernel_ms(m17gpu_ctx *ctx, float h_ms[4], int *h_calls);

@@ -145,7 +145,7 @@ class Receiver:
         _check(lib().m17gpu_set_profiling(self._ctx, int(bool(on))), "m17gpu_set_profiling")
 
     def kernel_ms(self):
-        """Average ms per launch of (k_frontend, k_sync_frame, k_decode, k_lsf), number of calls."""
+        """Average ms per launch of (k_frontend, k_sync_frame, k_worklist + k_decode, k_bookkeeping), number of calls."""
         ms = (C.c_float * 4)()
         n = C.c_int()
         _check(lib().m17gpu_get_kernel_ms(self._ctx, ms, C.byref(n)), "m17gpu_get_kernel_ms")
