@@ -87,6 +87,14 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C m17_sdr_amd/csrc` (hipcc, gfx950).  There is no CPU fallback.")
+    # PyTorch ships its own libamdhip64; the Python host layer hands torch device pointers to
+    # this library, so both must sit on ONE HIP runtime: let torch load its copy first (the
+    # SONAME then resolves to it).  Loaded the other way round the process ends up with two
+    # runtimes and m17gpu_create sees no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError if the .so lacks a declared symbol

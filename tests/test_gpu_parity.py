@@ -257,3 +257,64 @@ def test_pluto_decimator_bit_exact_and_streaming():
                                                oracle.vp(want))
                 np.testing.assert_array_equal(got[c], want)
         rx.close()
+
+
+def _compare_raw(iq, mode, rec_cap=None, options=None):
+    """GPU vs oracle on caller-made IQ.  NaNs (0,0 samples limit to NaN in the reference too)
+    compare as equal whatever their payload; everything else bit for bit."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    C, nblk = iq.shape[0], iq.shape[1]
+    rx = m.Receiver(C, nblk)
+    for k, v in (options or {}).items():
+        rx.set_option(k, v)
+    out = rx.rx_blocks(torch.from_numpy(iq).cuda(), mode, rx.alloc_outputs(nblk, rec_cap=rec_cap, want_syms=True))
+    torch.cuda.synchronize()
+    ref = oracle.Channels(C).rx_blocks(iq, mode=mode, cap=rec_cap)
+    np.testing.assert_array_equal(out["nsyms"].cpu().numpy(), ref["nsyms"])
+    gs, rs = out["syms"].cpu().numpy(), ref["syms"]
+    both_nan = np.isnan(gs) & np.isnan(rs)
+    np.testing.assert_array_equal(np.where(both_nan, 0, gs.view(np.uint32)), np.where(both_nan, 0, rs.view(np.uint32)))
+    counts = out["counts"].cpu().numpy()
+    np.testing.assert_array_equal(counts, ref["counts"])
+    recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1).copy()
+    rr = ref["recs"].copy()
+    for a in (recs, rr):
+        a["variance"][np.isnan(a["variance"])] = 0.0
+    for c in range(C):
+        n = min(counts[c], recs.shape[1])
+        assert recs[c, :n].tobytes() == rr[c, :n].tobytes(), (c, recs[c, :n], rr[c, :n])
+    rx.close()
+    return counts, recs
+
+
+def test_hostile_input_zero_saturated_and_noise():
+    """Squelched (all-zero) blocks, full-scale and alternating-extreme samples, white noise:
+    nothing the generator makes, everything a radio can hand over."""
+    import m17_sdr_amd as m
+    rng = np.random.default_rng(7)
+    C, nblk = 24, 10
+    sig = m.generate_batch(C, nblk, n_stream_frames=30, ebn0_db=200.0)
+    iq = sig["iq"].copy()
+    iq[0] = 0                                             # a dead channel
+    iq[1, 3:6] = 0                                        # squelch gap inside a transmission
+    iq[2, :, ::7] = 0                                     # isolated zero samples
+    iq[3] = 32767
+    iq[4] = -32768
+    iq[5, :, ::2] = 32767; iq[5, :, 1::2] = -32768
+    iq[6] = rng.integers(-32768, 32768, size=iq[6].shape, dtype=np.int16)
+    iq[7] = rng.integers(-3, 4, size=iq[7].shape, dtype=np.int16)      # tiny amplitudes incl. (0,0)
+    iq[8, 5, 100:130] = 0
+    _compare_raw(np.ascontiguousarray(iq), mode=1)
+    _compare_raw(np.ascontiguousarray(iq), mode=0, options={"sync_impl": 4, "lanes_per_channel": 16})
+
+
+def test_record_capacity_overflow_and_max_blocks():
+    """More framer events than rec_cap: the count keeps running, the first rec_cap records are
+    kept; and one channel at the context's full block count."""
+    import m17_sdr_amd as m
+    sig = m.generate_batch(6, 20, n_stream_frames=40, ebn0_db=200.0)
+    counts, _ = _compare_raw(np.ascontiguousarray(sig["iq"]), mode=1, rec_cap=5)
+    assert counts.max() > 5
+    sig = m.generate_batch(1, 64, n_stream_frames=70, ebn0_db=12.0)
+    _compare_raw(np.ascontiguousarray(sig["iq"]), mode=1)
