@@ -213,6 +213,16 @@ uint64_t m17gen_encode_call(const char *call9);
 /* modulate n dibits (value 0..3, or 255 = zero deviation) appending 10 samples each */
 int m17gen_modulate(const uint8_t *dibits, int n, int16_t *h_iq, int reset);
 
+/* GPU-side signal source: the signal of m17gen_batch (stream mode) for the
+ * context's C channels, made on the device: d_iq [C][nblk][1920][2] int16; optional d_lsf
+ * [C][30], d_payload [C][max_payload_frames][16], d_nframes [C].  Restates m17_tx_routines.cpp:24-255
+ * and m17_modulate.cpp:22-86 like the host generator; dibits, filter sums and phases are
+ * bit-identical to it, cos/sin/log come from the device math library (an IQ sample may differ by
+ * one LSB with probability ~1e-12).  Synchronises the stream before returning. */
+int m17gpu_gen_batch(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int nblk, int n_stream_frames,
+                     float ebn0_db, float noise_cutoff_hz, int16_t *d_iq, uint8_t *d_lsf, uint8_t *d_payload,
+                     int max_payload_frames, int32_t *d_nframes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,7 @@ SIGNATURES = {
     "m17gen_build_lsf": (_i, [_u64, _u64, C.c_uint16, _vp, _vp]),
     "m17gen_encode_call": (_u64, [C.c_char_p]),
     "m17gen_modulate": (_i, [_vp, _i, _vp, _i]),
+    "m17gpu_gen_batch": (_i, [_vp, _u64, _i, _i, _i, C.c_float, C.c_float, _vp, _vp, _vp, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -99,6 +99,22 @@ class Receiver:
                "m17gpu_sync_frame")
         return out
 
+    def gen_batch(self, nblk, n_stream_frames=40, ebn0_db=200.0, base_seed=0x4D313700, first_channel=0,
+                  noise_cutoff_hz=0.0):
+        """GPU-side signal source (stream mode): the same signal as generate_batch, made on the device.
+        Returns dict(iq[C,nblk,1920,2] int16 cuda, lsf[C,30], payload[C,F,16], nframes[C]) of cuda tensors."""
+        import torch
+        dev = f"cuda:{self.device}"
+        max_frames = nblk + 2
+        iq = torch.empty((self.C, nblk, 1920, 2), dtype=torch.int16, device=dev)
+        lsf = torch.zeros((self.C, 30), dtype=torch.uint8, device=dev)
+        pl = torch.zeros((self.C, max_frames, 16), dtype=torch.uint8, device=dev)
+        nf = torch.zeros((self.C,), dtype=torch.int32, device=dev)
+        _check(lib().m17gpu_gen_batch(self._ctx, base_seed, first_channel, nblk, n_stream_frames, ebn0_db,
+                                      noise_cutoff_hz, _ptr(iq), _ptr(lsf), _ptr(pl), max_frames, _ptr(nf), _stream()),
+               "m17gpu_gen_batch")
+        return {"iq": iq, "lsf": lsf, "payload": pl, "nframes": nf}
+
     def pluto_decimate(self, wide):
         """wide: int16 cuda tensor [C, n_in, 2] at 384 kHz -> [C, n_in/8, 2] at 48 kHz (radio.cpp:18-40)."""
         import torch

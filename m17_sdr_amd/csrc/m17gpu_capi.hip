@@ -8,7 +8,10 @@
 #include "m17_decode_chan.hip"
 #include "m17_decode_quad.hip"
 #include "m17_pluto.hip"
+#include "m17_gen.hip"
 #include "m17_host.h"
+#include <cmath>
+#include <algorithm>
 #include "../../include/m17gpu.h"
 #include <string>
 #include <algorithm>
@@ -434,6 +437,73 @@ int m17gpu_pluto_decimate(m17gpu_ctx *ctx, const int16_t *d_in, int n_in, int16_
     hipLaunchKernelGGL(k_pluto_hist, dim3(cdiv((long long)ctx->C * 32, 256)), dim3(256), 0, st,
                        reinterpret_cast<const uint32_t *>(d_in), ctx->d_dec_hist, n_in, ctx->C);
     HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+// GPU-side signal source: same arguments and the same signal as m17gen_batch
+// (stream mode), written to device memory.  Channels are generated in groups so that the fp32
+// phase workspace stays below 1 GiB.
+int m17gpu_gen_batch(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int nblk, int n_stream_frames,
+                     float ebn0_db, float noise_cutoff_hz, int16_t *d_iq, uint8_t *d_lsf, uint8_t *d_payload,
+                     int max_payload_frames, int32_t *d_nframes, void *stream)
+{
+    if (!ctx || !d_iq || nblk <= 0 || n_stream_frames < 0 || (d_payload && max_payload_frames <= 0))
+        return fail(M17GPU_ERR_ARG, "m17gpu_gen_batch: bad argument");
+    hipStream_t st = S(stream);
+    const long long want = (long long)nblk * kBlockSamples;
+    // modulator taps and deviations exactly as the host generator builds them (m17_modulate.cpp:9,73-74)
+    float taps[310];
+    m17::build_rrc(taps, 0.5f, 310, 10);
+    m17::set_filter_gain(taps, 10, 1, 310);
+    GenArgs A;
+    A.base_seed = base_seed; A.nblk = nblk; A.n_stream_frames = n_stream_frames; A.nslots = nblk + 1;
+    A.lut[0] = (float)(M_PI / 30.0); A.lut[1] = (float)(M_PI / 10.0);
+    A.lut[2] = (float)(-M_PI / 30);  A.lut[3] = (float)(-M_PI / 10.0);
+    NoiseArgs NZ;
+    std::memset(&NZ, 0, sizeof NZ);
+    if (ebn0_db < 100.0f) {
+        const double esn0 = 2.0 * std::pow(10.0, ebn0_db / 10.0), a = 16383.0;
+        NZ.on = 1;
+        NZ.sigma = std::sqrt(a * a * 10 / (2.0 * esn0));
+        if (noise_cutoff_hz > 0.0f) {
+            constexpr int L = 63;
+            double hs = 0.0;
+            const double fc = (double)noise_cutoff_hz / 48000.0;
+            for (int k = 0; k < L; ++k) {
+                const int m = k - L / 2;
+                const double sinc = (m == 0) ? 2.0 * fc : std::sin(2.0 * M_PI * fc * m) / (M_PI * m);
+                NZ.h[k] = sinc * (0.54 - 0.46 * std::cos(2.0 * M_PI * k / (L - 1)));
+                hs += NZ.h[k];
+            }
+            for (int k = 0; k < L; ++k) NZ.h[k] /= hs;
+            NZ.taps = L;
+        }
+    }
+    int group = (int)std::max(1ll, (1ll << 30) / (want * 4));
+    if (group > ctx->C) group = ctx->C;
+    float *d_taps = nullptr, *d_sum = nullptr;
+    uint8_t *d_sym = nullptr;
+    HIPCHK(hipMalloc(&d_taps, sizeof taps));
+    HIPCHK(hipMemcpyAsync(d_taps, taps, sizeof taps, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMalloc(&d_sum, sizeof(float) * (size_t)group * want));
+    HIPCHK(hipMalloc(&d_sym, (size_t)group * A.nslots * 192));
+    if (d_nframes) HIPCHK(hipMemsetAsync(d_nframes, 0, sizeof(int32_t) * (size_t)ctx->C, st));
+    for (int c0 = 0; c0 < ctx->C; c0 += group) {
+        const int cn = std::min(group, ctx->C - c0);
+        A.first_channel = first_channel + c0; A.C = cn;
+        hipLaunchKernelGGL(k_gen_symbols, dim3(cdiv((long long)cn * A.nslots, 64)), dim3(64), 0, st, A, ctx->d_genc, d_sym,
+                           d_lsf ? d_lsf + (size_t)c0 * 30 : nullptr,
+                           d_payload ? d_payload + (size_t)c0 * max_payload_frames * 16 : nullptr, max_payload_frames,
+                           d_nframes ? d_nframes + c0 : nullptr);
+        hipLaunchKernelGGL(k_gen_sum, dim3(cdiv((long long)cn * want, 256)), dim3(256), 0, st, A, d_sym, d_taps, d_sum);
+        hipLaunchKernelGGL(k_gen_phase, dim3(cdiv(cn, 64)), dim3(64), 0, st, A, d_sum);
+        const int segs = (int)((want + GEN_SEG - 1) / GEN_SEG);
+        hipLaunchKernelGGL(k_gen_iq, dim3((unsigned)((long long)cn * segs)), dim3(GEN_SEG), 0, st, A, NZ, d_sum,
+                           d_iq + (size_t)c0 * want * 2);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(st));                       // the workspace is freed here
+    (void)hipFree(d_taps); (void)hipFree(d_sum); (void)hipFree(d_sym);
     return M17GPU_OK;
 }
 

@@ -318,3 +318,33 @@ def test_record_capacity_overflow_and_max_blocks():
     assert counts.max() > 5
     sig = m.generate_batch(1, 64, n_stream_frames=70, ebn0_db=12.0)
     _compare_raw(np.ascontiguousarray(sig["iq"]), mode=1)
+
+
+@pytest.mark.parametrize("ebn0,cutoff", [(200.0, 0.0), (9.0, 0.0), (8.0, 6250.0)])
+def test_gpu_signal_source_matches_host_generator(ebn0, cutoff):
+    """the device generator makes the host generator's signal.  Frame bits, filter sums
+    and phases are the same arithmetic; cos/sin/log come from different math libraries, so an IQ
+    sample may differ by one LSB (expected about never) -- and the decoded records must be identical."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    C, nblk, nsf = 37, 14, 9
+    host = m.generate_batch(C, nblk, n_stream_frames=nsf, ebn0_db=ebn0, noise_cutoff_hz=cutoff, first_channel=5)
+    rx = m.Receiver(C, nblk)
+    dev = rx.gen_batch(nblk, n_stream_frames=nsf, ebn0_db=ebn0, noise_cutoff_hz=cutoff, first_channel=5)
+    torch.cuda.synchronize()
+    giq = dev["iq"].cpu().numpy()
+    diff = np.abs(giq.astype(np.int32) - host["iq"].astype(np.int32))
+    assert diff.max() <= 1, int(diff.max())
+    assert (diff != 0).mean() < 1e-6, float((diff != 0).mean())
+    np.testing.assert_array_equal(dev["lsf"].cpu().numpy(), host["lsf"])
+    np.testing.assert_array_equal(dev["nframes"].cpu().numpy(), host["nframes"])
+    np.testing.assert_array_equal(dev["payload"].cpu().numpy(), host["payload"])
+    out = rx.rx_blocks(dev["iq"], 1, rx.alloc_outputs(nblk))
+    torch.cuda.synchronize()
+    ref = oracle.Channels(C).rx_blocks(host["iq"], mode=1, want_syms=False)
+    counts = out["counts"].cpu().numpy()
+    np.testing.assert_array_equal(counts, ref["counts"])
+    recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
+    for c in range(C):
+        assert recs[c, :counts[c]].tobytes() == ref["recs"][c, :counts[c]].tobytes()
+    rx.close()
