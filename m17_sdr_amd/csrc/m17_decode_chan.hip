@@ -42,6 +42,19 @@ __device__ __forceinline__ uint32_t crc30_wave(const uint8_t *p, const uint16_t 
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)(v ^ 0x1B73u));   // 0x1B73 = crc of 30 zero bytes
 }
 
+// same CRC with the 30 bytes held one per lane and the lane's 8 basis words in registers
+__device__ __forceinline__ uint32_t crc30_reg(uint32_t byte, uint4 bv, int lane)
+{
+    uint32_t v = 0;
+    if (lane < 30) {
+        const uint32_t w[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v ^= (byte >> k & 1u) ? ((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) : 0u;
+    }
+    v = xor_reduce32(v);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(v ^ 0x1B73u));
+}
+
 struct alignas(16) LsfShared {
     uint16_t basis[240];
     uint16_t crc[256];
@@ -121,12 +134,18 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
     uint32_t g_errors = (uint32_t)uni((int)cs.g_errors), n_frames = (uint32_t)uni((int)cs.n_frames);
     uint32_t in_frame = (uint32_t)uni((int)cs.in_frame), epoch = (uint32_t)uni((int)cs.frame_id_epoch);
     int packet_idx = uni(cs.packet_idx);
-    bool lsf1_ok = crc30_wave(ls.lsf[1], ls.basis, lane) == 0;          // m_lsf[1] only ever changes to CRC-good content
+    // m_lsf[0] / m_lsf[1] live one byte per lane in registers for the replay (lanes 0..29), and so do
+    // the lane's eight CRC basis words: a LICH update and its CRC need no LDS round trip
+    uint32_t b0 = (lane < 30) ? ls.lsf[0][lane] : 0u, b1 = (lane < 30) ? ls.lsf[1][lane] : 0u;
+    const uint4 bv = (lane < 30) ? reinterpret_cast<const uint4 *>(ls.basis)[lane] : make_uint4(0u, 0u, 0u, 0u);
+    bool lsf1_ok = crc30_reg(b1, bv, lane) == 0;                         // m_lsf[1] only ever changes to CRC-good content
     bool gate_ok = crc30_wave(ls.packet, ls.basis, lane) == 0;           // decode_link_frame's quirk (m17_rx_parse.cpp:98)
+    uint32_t wnext = (n > 0 && lane < 16) ? reinterpret_cast<const uint32_t *>(&rsrc[0])[lane] : 0u;
     for (int i = 0; i < n; ++i) {
         const uint32_t *r = reinterpret_cast<const uint32_t *>(&rsrc[i]);
-        // lanes 0..15 fetch the record words, everything below is wave-uniform
-        const uint32_t wv = (lane < 16) ? r[lane] : 0u;
+        // lanes 0..15 hold the record words (fetched one record ahead), everything below is wave-uniform
+        const uint32_t wv = wnext;
+        if (i + 1 < n && lane < 16) wnext = reinterpret_cast<const uint32_t *>(&rsrc[i + 1])[lane];
         const uint32_t w0 = (uint32_t)bcast_lane_i((int)wv, 0), w1 = (uint32_t)bcast_lane_i((int)wv, 1);
         uint32_t flags = w1 & 0xFFFF;
         const int type = (int)(w0 & 0xFF);
@@ -144,11 +163,10 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
             const uint32_t d0 = (uint32_t)bcast_lane_i((int)wv, 5), d1 = (uint32_t)bcast_lane_i((int)wv, 6);
             const int seq = (int)((d1 >> 8 & 0xFF) >> 5);
             if (seq < 6) {
-                if (lane < 5) ls.lsf[0][seq * 5 + lane] = (uint8_t)((lane < 4) ? (d0 >> (8 * lane)) : d1);
-                group_sync();
-                if (crc30_wave(ls.lsf[0], ls.basis, lane) == 0) {
-                    if (lane < 30) ls.lsf[1][lane] = ls.lsf[0][lane];
-                    group_sync();
+                const int k = lane - seq * 5;                               // byte k of the chunk lands in lane seq*5 + k
+                if (k >= 0 && k < 5) b0 = ((k < 4) ? (d0 >> (8 * k)) : d1) & 0xFFu;
+                if (crc30_reg(b0, bv, lane) == 0) {
+                    b1 = b0;
                     lsf1_ok = true;
                     flags |= M17_F_LICH_OK;
                 }
@@ -181,6 +199,7 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
             reinterpret_cast<uint32_t *>(&crecs[i])[1] = (w1 & 0xFFFF0000u) | flags;
     }
     // ---- state back
+    if (lane < 30) { ls.lsf[0][lane] = (uint8_t)b0; ls.lsf[1][lane] = (uint8_t)b1; }
     if (lane == 0) {
         cs.g_errors = g_errors; cs.n_frames = n_frames; cs.in_frame = in_frame; cs.frame_id_epoch = epoch;
         cs.packet_idx = packet_idx;

@@ -57,7 +57,7 @@ __device__ __forceinline__ SyncResult sync_check_grp(const float v[8], int gl, i
 #pragma unroll
     for (int i = 1; i < 8; ++i) mine = (gl == i) ? v[i] : mine;
     const bool bad = (gl < 8) && ((nm >> gl & 1u) ? (mine > 0.0f) : (mine < 0.0f));
-    const int votes = (int)__popcll((__ballot(bad) >> gshift) & GrpCfg<LPC>::MASK);
+    const int votes = (int)__popcll((__builtin_amdgcn_ballot_w64(bad) >> gshift) & GrpCfg<LPC>::MASK);
     float mmin = fabsf(v[0]), mmax = mmin;
 #pragma unroll
     for (int i = 1; i < 8; ++i) {
@@ -129,11 +129,11 @@ __device__ __forceinline__ void timing_pass(GrpChan &my, const float4 (&tp)[16],
             const int inst = gl + LPC * j;
             const bool vote_ok = (gl < nv) && (p + 2 * inst + 1 < kDiscOut);
             const float dd = (s[j] < 0.0f) ? -d[j] : d[j];
-            const unsigned long long um = (__ballot(vote_ok && dd > 0.0f) >> gshift) & Cfg::MASK;
-            const unsigned long long dm = (__ballot(vote_ok && dd < 0.0f) >> gshift) & Cfg::MASK;
+            const unsigned long long um = (__builtin_amdgcn_ballot_w64(vote_ok && dd > 0.0f) >> gshift) & Cfg::MASK;
+            const unsigned long long dm = (__builtin_amdgcn_ballot_w64(vote_ok && dd < 0.0f) >> gshift) & Cfg::MASK;
             const int tk = thr + (int)__popcll(um & incl) - (int)__popcll(dm & incl);
             const unsigned long long cr =
-                (__ballot(vote_ok && (tk > thresh || tk < -thresh)) >> gshift) & Cfg::MASK;
+                (__builtin_amdgcn_ballot_w64(vote_ok && (tk > thresh || tk < -thresh)) >> gshift) & Cfg::MASK;
             const int kl = cr ? (int)__ffsll((long long)cr) - 1 : 0;
             const int naccept = cr ? kl + 1 : nv;
             if (gl < naccept && (m_idx + gl) >= 0) my.h[8 + m_idx + gl] = s[j];
@@ -335,7 +335,7 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
                 unsigned long long hm = 0;
                 SyncResult r; r.type = 0; r.votes = 8; r.variance = 1.0f;
                 if (cand && hunt_compatible(v)) r = sync_check(v);           // most windows are rejected by sign
-                hm = (__ballot(cand && sync_accept(r, false)) >> gshift) & Cfg::MASK;
+                hm = (__builtin_amdgcn_ballot_w64(cand && sync_accept(r, false)) >> gshift) & Cfg::MASK;
                 if (hm) {
                     const int l = (int)__ffsll((long long)hm) - 1;
                     const int js = pos + l;
