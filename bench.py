@@ -36,17 +36,25 @@ def parse_args():
     ap.add_argument("--blocks", type=int, default=50, help="1920-sample blocks per channel per step (2 s)")
     ap.add_argument("--workload", choices=["frontend", "full"], default="frontend")
     ap.add_argument("--ebn0", type=float, default=200.0, help="AWGN level of the synthetic IQ (>=100: none)")
-    ap.add_argument("--unique", type=int, default=256, help="distinct generated channels (tiled to --channels)")
+    ap.add_argument("--unique", type=int, default=256, help="host generator: distinct generated channels (tiled to --channels)")
+    ap.add_argument("--gen", choices=["gpu", "host"], default="gpu",
+                    help="signal source: m17gpu_gen_batch on the device (every channel distinct) or the host generator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-syms", action="store_true", help="front end: do not write the symbol stream")
     return ap.parse_args()
 
 
-def make_input(args, rank, torch):
-    """Synthetic IQ for this rank's channel shard, generated on the host by the
-    library's transmitter restatement, tiled to C channels, resident in HBM."""
+def make_input(args, rank, torch, rx):
+    """Synthetic IQ for this rank's channel shard, resident in HBM before the timed region:
+    made on the device by m17gpu_gen_batch (default; SURVEY 8f-1, every channel distinct, seeded by
+    global channel id), or on the host by the same transmitter restatement and tiled to C channels.
+    Returns (device IQ, host copy of the first <= 256 channels for the CPU baseline)."""
     import m17_sdr_amd as m
     C, nblk = args.channels, args.blocks
+    if args.gen == "gpu":
+        dev = rx.gen_batch(nblk, n_stream_frames=40, ebn0_db=args.ebn0, first_channel=rank * C)["iq"]
+        torch.cuda.synchronize()
+        return dev, {"iq": dev[:min(256, C)].cpu().numpy()}
     uniq = min(args.unique, C)
     nthreads = max(1, min(16, (os.cpu_count() or 8) // max(1, args.gpus)))
     sig = m.generate_batch(uniq, nblk, n_stream_frames=40, ebn0_db=args.ebn0,
@@ -115,8 +123,8 @@ def main():
 
     C, nblk = args.channels, args.blocks
     mode = 0 if args.workload == "frontend" else 1
-    iq, sig = make_input(args, rank, torch)
     rx = m.Receiver(C, nblk, device=local)
+    iq, sig = make_input(args, rank, torch, rx)
     out = rx.alloc_outputs(nblk, want_syms=(mode == 0 and not args.no_syms))
 
     def barrier():
@@ -170,6 +178,7 @@ def main():
                                 "full chain incl. soft Viterbi + depuncture/deinterleave/Golay (BASELINE configs[2])"),
                    "channels_per_gpu": C, "blocks_per_step": nblk, "samples_per_block": 1920,
                    "realtime_channels": int(msym * 1e6 / 4800), "ebn0_db": args.ebn0,
+                   "signal_source": "m17gpu_gen_batch (device)" if args.gen == "gpu" else "m17gen_batch (host, tiled)",
                    "parallelism": f"channel-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -318,27 +318,18 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
 #endif
 }
 
-// the in-order bookkeeping of k_decode_chan as its own kernel: one wave per channel.  The
-// channel's records are staged in LDS first -- read one by one from HBM the 51 dependent
-// loads alone cost 50 us.
+// the in-order bookkeeping of k_decode_chan as its own kernel: one wave per channel
 __global__ __launch_bounds__(64)
 void k_book_chan(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs, int rec_cap,
-                 const int32_t *__restrict__ counts, const uint16_t *__restrict__ crc_basis, int staged)
+                 const int32_t *__restrict__ counts, const uint16_t *__restrict__ crc_basis)
 {
     __shared__ LsfShared ls;
-    extern __shared__ __attribute__((aligned(16))) uint32_t rec_stage[];      // [rec_cap][16] dwords
     const int lane = lane_id(), chan = (int)blockIdx.x;
     ChanState &cs = st[chan];
     m17gpu_rec_dev *crecs = recs + (size_t)chan * rec_cap;
-    const int n = min(counts[chan], rec_cap);
-    if (staged) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(crecs);
-        uint4 *dst = reinterpret_cast<uint4 *>(rec_stage);
-        for (int q = lane; q < n * 4; q += 64) dst[q] = src[q];
-    }
     lsf_shared_init(ls, cs, crc_basis, lane, 64);
     group_sync();
-    bookkeeping_wave(cs, crecs, staged ? reinterpret_cast<const m17gpu_rec_dev *>(rec_stage) : crecs, n, ls, lane);
+    bookkeeping_wave(cs, crecs, crecs, min(counts[chan], rec_cap), ls, lane, crc_basis);
 }
 
 } // namespace m17dev

@@ -86,19 +86,28 @@ int upload_tables(m17gpu_ctx *ctx)
     HIPCHK(hipMalloc(&ctx->d_gerr, 4096 * sizeof(uint16_t)));
     HIPCHK(hipMemcpy(ctx->d_genc, T.golay_enc, 4096 * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->d_gerr, T.golay_err, 4096 * sizeof(uint16_t), hipMemcpyHostToDevice));
-    // CRC-16 basis for the lane-parallel 30-byte CRC: word of a message whose only set bit is bit k of byte i
-    uint16_t basis[240];
-    for (int i = 0; i < 30; ++i)
-        for (int k = 0; k < 8; ++k) {
-            uint8_t msg[30] = {0};
-            msg[i] = (uint8_t)(1u << k);
-            basis[i * 8 + k] = (uint16_t)(m17::crc16(msg, 30) ^ 0x1B73);    // remove the init-value term
-        }
+    // CRC-16 is linear over GF(2): crc(msg) = crc(len zero bytes) xor XOR over set bits of E[distance from the end][bit].
+    // Layout of d_crc_basis: [240] the 30-byte case as (byte i, bit k) | [801] Z[L] = crc of L zero bytes |
+    // [800][8] E[p][k] for messages up to the 800-byte packet buffer (m17_rx_parse.cpp:6).
+    std::vector<uint16_t> basis(240 + 801 + 6400);
+    {
+        std::vector<uint8_t> msg(801, 0);
+        uint16_t *Z = &basis[240], *E = &basis[240 + 801];
+        for (int L = 0; L <= 800; ++L) Z[L] = m17::crc16(msg.data(), L);
+        for (int p_ = 0; p_ < 800; ++p_)
+            for (int k = 0; k < 8; ++k) {
+                msg[0] = (uint8_t)(1u << k);
+                E[p_ * 8 + k] = (uint16_t)(m17::crc16(msg.data(), p_ + 1) ^ Z[p_ + 1]);
+            }
+        msg[0] = 0;
+        for (int i = 0; i < 30; ++i)
+            for (int k = 0; k < 8; ++k) basis[i * 8 + k] = E[(29 - i) * 8 + k];
+    }
     int16_t dec[32] = {0};
     m17::build_pluto_dec_filter(dec);
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_dec), dec, sizeof dec));
-    HIPCHK(hipMalloc(&ctx->d_crc_basis, sizeof basis));
-    HIPCHK(hipMemcpy(ctx->d_crc_basis, basis, sizeof basis, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&ctx->d_crc_basis, basis.size() * sizeof(uint16_t)));
+    HIPCHK(hipMemcpy(ctx->d_crc_basis, basis.data(), basis.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     return M17GPU_OK;
 }
 
@@ -295,9 +304,8 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
                                ctx->d_genc, ctx->d_gerr);
             HIPCHK(hipGetLastError());
             MARK(3);
-            const int staged = (size_t)rec_cap * 64 <= 48 * 1024;         // records of one channel in LDS
-            hipLaunchKernelGGL(k_book_chan, dim3(ctx->C), dim3(64), staged ? (size_t)rec_cap * 64 : 0, st, ctx->d_state,
-                               reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->d_crc_basis, staged);
+            hipLaunchKernelGGL(k_book_chan, dim3(ctx->C), dim3(64), 0, st, ctx->d_state,
+                               reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->d_crc_basis);
             HIPCHK(hipGetLastError());
             MARK(4);
         } else if (ctx->decode_impl == 1) {
