@@ -45,16 +45,25 @@ def parse_args():
 
 
 def make_input(args, rank, torch, rx):
-    """Synthetic IQ for this rank's channel shard, resident in HBM before the timed region:
-    made on the device by m17gpu_gen_batch (default; SURVEY 8f-1, every channel distinct, seeded by
-    global channel id), or on the host by the same transmitter restatement and tiled to C channels.
-    Returns (device IQ, host copy of the first <= 256 channels for the CPU baseline)."""
+    """Synthetic IQ for this rank's channel shard, resident in HBM before the timed region.
+    Default: ONE continuous signal per channel, (warmup + steps) x blocks long, made on the device
+    by m17gpu_gen_batch (every channel distinct, seeded by global channel id) and
+    cut into per-step slabs [step][C][blocks] -- each step receives the next 2 s of every
+    channel, as a live receiver would, instead of the same 2 s again (which breaks the frame
+    phase at every step boundary and sends the framer hunting).  --gen host: the host generator,
+    tiled to C channels, the same slab every step.
+    Returns (list of per-step device tensors, host copy of <= 256 channels of the first timed slab)."""
     import m17_sdr_amd as m
     C, nblk = args.channels, args.blocks
+    T = args.warmup + args.steps
     if args.gen == "gpu":
-        dev = rx.gen_batch(nblk, n_stream_frames=40, ebn0_db=args.ebn0, first_channel=rank * C)["iq"]
+        big = rx.gen_batch(nblk * T, n_stream_frames=40, ebn0_db=args.ebn0, first_channel=rank * C)["iq"]
         torch.cuda.synchronize()
-        return dev, {"iq": dev[:min(256, C)].cpu().numpy()}
+        slabs = big.view(C, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4).contiguous()
+        del big
+        torch.cuda.empty_cache()
+        steps = [slabs[k] for k in range(T)]
+        return steps, {"iq": steps[args.warmup][:min(256, C)].cpu().numpy()}
     uniq = min(args.unique, C)
     nthreads = max(1, min(16, (os.cpu_count() or 8) // max(1, args.gpus)))
     sig = m.generate_batch(uniq, nblk, n_stream_frames=40, ebn0_db=args.ebn0,
@@ -64,7 +73,7 @@ def make_input(args, rank, torch, rx):
     for c0 in range(0, C, uniq):
         n = min(uniq, C - c0)
         dev[c0:c0 + n].copy_(host[:n], non_blocking=False)
-    return dev, sig
+    return [dev] * T, sig
 
 
 def cpu_baseline(args, sig):
@@ -133,13 +142,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        rx.rx_blocks(iq, mode, out)
+    for k in range(args.warmup):
+        rx.rx_blocks(iq[k], mode, out)
     barrier()
     rx.set_profiling(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rx.rx_blocks(iq, mode, out)
+    for k in range(args.steps):
+        rx.rx_blocks(iq[args.warmup + k], mode, out)
     barrier()
     dt = time.perf_counter() - t0
     rx.set_profiling(False)
@@ -178,7 +187,8 @@ def main():
                                 "full chain incl. soft Viterbi + depuncture/deinterleave/Golay (BASELINE configs[2])"),
                    "channels_per_gpu": C, "blocks_per_step": nblk, "samples_per_block": 1920,
                    "realtime_channels": int(msym * 1e6 / 4800), "ebn0_db": args.ebn0,
-                   "signal_source": "m17gpu_gen_batch (device)" if args.gen == "gpu" else "m17gen_batch (host, tiled)",
+                   "signal_source": ("m17gpu_gen_batch (device), one continuous %.0f s stream per channel cut into steps" % (0.04 * nblk * (args.warmup + args.steps))
+                                     if args.gen == "gpu" else "m17gen_batch (host, tiled), the same slab every step"),
                    "parallelism": f"channel-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -384,6 +384,7 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
 
 #ifdef M17_STAMPS
     if (chan == 0 && gl == 0) for (int i = 0; i < 12; ++i) g_stamps[i] = acc_[i];
+    if (chan < 4096 && gl == 0) { for (int i = 0; i < 6; ++i) g_chan_stamps[chan][i] = acc_[i]; g_chan_stamps[chan][6] = acc_[8]; g_chan_stamps[chan][7] = acc_[10]; }
 #endif
     // ---- store state
     if (gl == 0) {

@@ -61,6 +61,7 @@ __device__ __forceinline__ void lds_barrier()
 
 #ifdef M17_STAMPS
 __device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_chan_stamps[4096][8];      // per channel: the phase accumulators of its wave
 #define DBGCNT(i) do { if (t == 0) atomicAdd(&g_stamps[12 + (i)], 1ull); } while (0)
 #define STAMP(i) do { unsigned long long now_; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \

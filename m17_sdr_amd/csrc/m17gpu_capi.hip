@@ -5,6 +5,7 @@
 #include "m17_sync_wave.hip"
 #include "m17_sync_ch.hip"
 #include "m17_sync_grp.hip"
+#include "m17_sync_ring.hip"
 #include "m17_decode_chan.hip"
 #include "m17_decode_quad.hip"
 #include "m17_pluto.hip"
@@ -144,11 +145,11 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
 {
     if (bcount < 0) bcount = nblk;
     int32_t *wl = ctx->decode_impl == 0 ? ctx->d_work : nullptr;      // the work list exists only for the legacy decode path
-    if (ctx->sync_impl == 4 && ctx->decode_impl != 0) {
+    if ((ctx->sync_impl == 4 || ctx->sync_impl == 5) && ctx->decode_impl != 0) {
         // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
         int lpc = ctx->lanes_per_channel;
         if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
-#define LAUNCH_GRP(L) hipLaunchKernelGGL(k_sync_frame_grp<L>, dim3(cdiv(ctx->C, GrpCfg<L>::CPW)), dim3(256), 0, st, \
+#define LAUNCH_GRP(L) hipLaunchKernelGGL((ctx->sync_impl == 5 ? k_sync_frame_ring<L> : k_sync_frame_grp<L>), dim3(cdiv(ctx->C, GrpCfg<L>::CPW)), dim3(256), 0, st, \
                            disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,                                  \
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,                        \
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms, ctx->d_fsym, b0, bcount)
@@ -160,7 +161,7 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
                            ctx->d_fsym, wl, ctx->d_nwork);
-    else if (ctx->sync_impl == 2 || ctx->sync_impl == 4)
+    else if (ctx->sync_impl == 2 || ctx->sync_impl == 4 || ctx->sync_impl == 5)
         hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(ctx->C, SW_WAVES)), dim3(64 * SW_WAVES), 0, st,
                            disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
@@ -339,6 +340,12 @@ int m17gpu_debug_stamps(unsigned long long *out)
 {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16));
+    return 0;
+}
+int m17gpu_debug_chan_stamps(unsigned long long *out /* [4096][8] */)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chan_stamps), sizeof(unsigned long long) * 4096 * 8));
     return 0;
 }
 #endif

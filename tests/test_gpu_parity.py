@@ -164,7 +164,8 @@ def test_exact_arithmetic_selftest():
 @pytest.mark.parametrize("options", [
     {"sync_impl": 0}, {"sync_impl": 1, "fast_windows": 0}, {"sync_impl": 1, "fast_windows": 1},
     {"sync_impl": 2}, {"sync_impl": 3}, {"sync_impl": 4, "lanes_per_channel": 64}, {"sync_impl": 4, "lanes_per_channel": 32},
-    {"sync_impl": 4, "lanes_per_channel": 16}, {"decode_impl": 0}, {"decode_impl": 1}, {"decode_impl": 2}, {"fe_impl": 1}, {"fe_impl": 2}])
+    {"sync_impl": 4, "lanes_per_channel": 16}, {"sync_impl": 5, "lanes_per_channel": 64}, {"sync_impl": 5, "lanes_per_channel": 32},
+    {"sync_impl": 5, "lanes_per_channel": 16}, {"decode_impl": 0}, {"decode_impl": 1}, {"decode_impl": 2}, {"fe_impl": 1}, {"fe_impl": 2}])
 def test_every_kernel_variant_is_bit_exact(options):
     _rx_compare(C=40, nblk=22, mode=1, ebn0=200.0, nsf=12, options=options)
     _rx_compare(C=40, nblk=9, mode=1, ebn0=9.0, nsf=5, calls=3, options=options)
