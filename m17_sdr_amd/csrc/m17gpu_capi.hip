@@ -457,7 +457,7 @@ int m17gpu_pluto_decimate(m17gpu_ctx *ctx, const int16_t *d_in, int n_in, int16_
 
 // GPU-side signal source: same arguments and the same signal as m17gen_batch
 // (stream mode), written to device memory.  Channels are generated in groups so that the fp32
-// phase workspace stays below 1 GiB.
+// phase workspace stays below 8 GiB.
 int m17gpu_gen_batch(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int nblk, int n_stream_frames,
                      float ebn0_db, float noise_cutoff_hz, int16_t *d_iq, uint8_t *d_lsf, uint8_t *d_payload,
                      int max_payload_frames, int32_t *d_nframes, void *stream)
@@ -494,7 +494,7 @@ int m17gpu_gen_batch(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int
             NZ.taps = L;
         }
     }
-    int group = (int)std::max(1ll, (1ll << 30) / (want * 4));
+    int group = (int)std::max(1ll, (8ll << 30) / (want * 4));   // the phase chain is one lane per channel: few, large groups
     if (group > ctx->C) group = ctx->C;
     float *d_taps = nullptr, *d_sum = nullptr;
     uint8_t *d_sym = nullptr;
