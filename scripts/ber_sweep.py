@@ -37,8 +37,11 @@ def main():
     ap.add_argument("--ebn0", type=float, nargs="*", default=[float(x) for x in range(0, 11)])
     ap.add_argument("--oracle-channels", type=int, default=512, help="channels per point also run through the CPU oracle")
     ap.add_argument("--noise-cutoff", type=float, default=6250.0, help="one-sided channel-filter cutoff applied to the noise, Hz (0 = white over 48 kHz)")
+    ap.add_argument("--gen", choices=["gpu", "host"], default="gpu", help="signal source (SURVEY 8f-1 device generator, or the host one)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
+    if a.gen == "gpu":
+        a.chunk = a.channels                      # the whole config in one launch, as BASELINE config #4 words it
     import torch
     import m17_sdr_amd as m
     from tests import oracle
@@ -48,16 +51,25 @@ def main():
         tot = dict(bit_err=0, bits=0, frames=0, sent=0, identical=True, checked=0)
         for c0 in range(0, a.channels, a.chunk):
             n = min(a.chunk, a.channels - c0)
-            sig = m.generate_batch(n, a.blocks, n_stream_frames=a.blocks - 6, ebn0_db=eb, first_channel=c0, nthreads=16,
-                                   noise_cutoff_hz=a.noise_cutoff)
             rx = m.Receiver(n, a.blocks)
-            out = rx.rx_blocks(torch.from_numpy(sig["iq"]).cuda(), 1, rx.alloc_outputs(a.blocks))
+            if a.gen == "gpu":
+                dsig = rx.gen_batch(a.blocks, n_stream_frames=a.blocks - 6, ebn0_db=eb, first_channel=c0,
+                                    noise_cutoff_hz=a.noise_cutoff)
+                iq_dev = dsig["iq"]
+                k0 = min(n, a.oracle_channels)
+                sig = {"payload": dsig["payload"].cpu().numpy(), "nframes": dsig["nframes"].cpu().numpy(),
+                       "iq": iq_dev[:k0].cpu().numpy()}
+            else:
+                sig = m.generate_batch(n, a.blocks, n_stream_frames=a.blocks - 6, ebn0_db=eb, first_channel=c0, nthreads=16,
+                                       noise_cutoff_hz=a.noise_cutoff)
+                iq_dev = torch.from_numpy(sig["iq"]).cuda()
+            out = rx.rx_blocks(iq_dev, 1, rx.alloc_outputs(a.blocks))
             torch.cuda.synchronize()
             recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(n, -1)
             counts = out["counts"].cpu().numpy()
             be, b, f, s = measure(recs, counts, sig, m)
             tot["bit_err"] += be; tot["bits"] += b; tot["frames"] += f; tot["sent"] += s
-            k = min(n, max(0, a.oracle_channels - tot["checked"]))
+            k = min(n, sig["iq"].shape[0], max(0, a.oracle_channels - tot["checked"]))
             if k:
                 ref = oracle.Channels(k).rx_blocks(np.ascontiguousarray(sig["iq"][:k]), mode=1, want_syms=False, nthreads=16)
                 same = np.array_equal(ref["counts"], counts[:k]) and all(
@@ -74,7 +86,7 @@ def main():
         rows.append(row)
         print(json.dumps(row), flush=True)
     if a.out:
-        json.dump({"channels": a.channels, "blocks": a.blocks, "noise_cutoff_hz": a.noise_cutoff, "points": rows}, open(a.out, "w"), indent=1)
+        json.dump({"channels": a.channels, "blocks": a.blocks, "noise_cutoff_hz": a.noise_cutoff, "signal_source": a.gen, "points": rows}, open(a.out, "w"), indent=1)
 
 
 if __name__ == "__main__":
