@@ -494,18 +494,7 @@ __device__ __forceinline__ bool sync_accept(const SyncResult &r, bool locked)
     return false;
 }
 
-// ---------------------------------------------------------------------------
-// k_sync_frame: one wave per channel
-// ---------------------------------------------------------------------------
-constexpr int SF_WAVES = 4;
-
-struct SfShared {
-    float x[kTaps - 1 + kDiscOut + 2];     // delay-line history (30) + this block's 384 inputs
-    float out[208];                        // m17_rx_sync_samples output of this block
-    float h[8 + 208];                      // m_sync (8) followed by the block's symbols
-    float f[kFrameSyms];                   // m_f_sym
-};
-
+// one 64-byte framer record, written by lanes 0..15 of the wave
 __device__ __forceinline__ void emit_record(m17gpu_rec_dev *recs, int rec_cap, int idx,
                                             uint32_t w0, uint32_t w1, float var, uint32_t block, uint32_t sympos)
 {
@@ -521,242 +510,6 @@ __device__ __forceinline__ void emit_record(m17gpu_rec_dev *recs, int rec_cap, i
         if (lane == 4) v = sympos;
         r[lane] = v;
     }
-}
-
-__global__ __launch_bounds__(64 * SF_WAVES)
-void k_sync_frame(const float *__restrict__ disc,     // [C][nblk][384]
-                  const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
-                  ChanState *__restrict__ st, int C, int nblk, int mode,
-                  m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
-                  float *__restrict__ syms, int32_t *__restrict__ nsyms,
-                  float *__restrict__ fsym,            // [C][rec_cap][192] frames to decode (mode 1)
-                  int32_t *__restrict__ work, int32_t *__restrict__ nwork)
-{
-    __shared__ SfShared sh_all[SF_WAVES];
-    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    const int chan = (int)blockIdx.x * SF_WAVES + wave;
-    if (chan >= C) return;                              // whole wave exits; no block-level barrier below
-    SfShared &sh = sh_all[wave];
-    ChanState &cs = st[chan];
-    m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
-
-    // ---- load state (wave-uniform scalars + LDS arrays)
-    int clk = uni(cs.clk), thr = uni(cs.thr), index = uni(cs.index);
-    float sum = unif(cs.sum), dif = unif(cs.dif);
-    int flock = uni(cs.flock), fclk = uni(cs.fclk), ferr = uni(cs.ferr);
-    uint32_t block_count = (uint32_t)uni((int)cs.block_count);
-    if (lane < kTaps - 1) sh.x[lane] = cs.buff[lane + 1];       // last 30 inputs
-    if (lane < 8) sh.h[lane] = cs.sync[lane];
-    for (int q = lane; q < kFrameSyms; q += 64) sh.f[q] = cs.fsym[q];
-    int nrec = 0;
-    size_t sym_base = (size_t)chan * M17_SYM_STRIDE(nblk);
-    int sym_total = 0;
-
-    for (int b = 0; b < nblk; ++b) {
-        // ---- stage the block's discriminator samples, DC removed (m17_dsp.cpp:217-219)
-        const float *src = disc + ((size_t)chan * nblk + b) * kDiscOut;
-        const float off = offs ? offs[(size_t)chan * nblk + b] : 0.0f;
-        for (int q = lane; q < kDiscOut; q += 64) {
-            const float v = src[q];
-            sh.x[kTaps - 1 + q] = offs ? (v - off) : v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-        // ---- timing recovery (m17_rx_sync.cpp:77-99), x[i .. i+30] is the delay line at input i
-        const int thresh = flock ? 80 : 10;
-        int p = 0, m_idx = 0;
-        while (p < kDiscOut) {
-            if (clk == 1) {
-                // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72)
-                clk = 0;
-                float d = (sum < 0.0f) ? -dif : dif;
-                if (d > 0.0f) thr++;
-                if (d < 0.0f) thr--;
-                if (thr > thresh) {
-                    index = (index + 1) % kPhases; thr = 0;
-                    if (index == 0) { clk = 1; if (m_idx >= 0 && lane == 0) sh.out[m_idx] = 0.0f; m_idx++; }
-                }
-                if (thr < -thresh) {
-                    thr = 0; index = (index + kPhases - 1) % kPhases;
-                    if (index == kPhases - 1) { clk = 1; m_idx--; }
-                }
-                p++;
-                continue;
-            }
-            // speculative pass: lane k is the filter tick at input p+2k and the vote tick after it
-            const int nf = min(64, (kDiscOut - p + 1) >> 1);
-            const int ik = p + 2 * lane;
-            const bool have = lane < nf;
-            float s = 0.0f, d = 0.0f;
-            {
-                const float *mf = c_tab.mf[index];
-                const float *md = c_tab.md[index];
-                const int base = have ? ik : p;
-                float xv = sh.x[base];
-                s = xv * mf[0];
-                d = xv * md[0];
-#pragma unroll
-                for (int j = 1; j < kTaps; ++j) {
-                    xv = sh.x[base + j];
-                    s += xv * mf[j];
-                    d += xv * md[j];
-                }
-            }
-            const bool vote_ok = have && (ik + 1 < kDiscOut);
-            const float dd = (s < 0.0f) ? -d : d;
-            const unsigned long long up = __ballot(vote_ok && dd > 0.0f);
-            const unsigned long long dn = __ballot(vote_ok && dd < 0.0f);
-            const unsigned long long incl = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-            const int tk = thr + __popcll(up & incl) - __popcll(dn & incl);
-            const unsigned long long cross = __ballot(vote_ok && (tk > thresh || tk < -thresh));
-            int naccept = nf;
-            int kstar = -1;
-            if (cross) { kstar = __ffsll((long long)cross) - 1; naccept = kstar + 1; }
-            if (lane < naccept && (m_idx + lane) >= 0) sh.out[m_idx + lane] = s;
-            m_idx += naccept;
-            sum = bcast_lane(s, naccept - 1);
-            dif = bcast_lane(d, naccept - 1);
-            if (cross) {
-                const int tstar = bcast_lane_i(tk, kstar);
-                thr = 0;
-                clk = 0;
-                if (tstar > thresh) {
-                    index = (index + 1) % kPhases;
-                    if (index == 0) { clk = 1; if (m_idx >= 0 && lane == 0) sh.out[m_idx] = 0.0f; m_idx++; }
-                } else {
-                    index = (index + kPhases - 1) % kPhases;
-                    if (index == kPhases - 1) { clk = 1; m_idx--; }
-                }
-                p = p + 2 * kstar + 2;
-            } else {
-                thr = thr + __popcll(up) - __popcll(dn);
-                const int ilast = p + 2 * (nf - 1);
-                if (ilast + 1 < kDiscOut) { clk = 0; p = ilast + 2; }
-                else { clk = 1; p = kDiscOut; }
-            }
-        }
-        const int n = m_idx > 0 ? m_idx : 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-        // delay line for the next block: last 30 inputs
-        {
-            float keep = 0.0f;
-            if (lane < kTaps - 1) keep = sh.x[kDiscOut + lane];
-            __builtin_amdgcn_wave_barrier();
-            if (lane < kTaps - 1) sh.x[lane] = keep;
-        }
-        // symbols out (optional) + framer input h[8+j]
-        for (int q = lane; q < n; q += 64) {
-            const float v = sh.out[q];
-            sh.h[8 + q] = v;
-            if (syms) syms[sym_base + sym_total + q] = v;
-        }
-        if (nsyms && lane == 0) nsyms[(size_t)chan * nblk + b] = n;
-        sym_total += n;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-        // ---- framer (m17_rx_frame.cpp:126-177)
-        int pos = 0;
-        while (pos < n) {
-            if (flock) {
-                const int t = min(kFrameSyms - fclk, n - pos);
-                for (int q = lane; q < t; q += 64) sh.f[fclk + q] = sh.h[8 + pos + q];
-                fclk += t; pos += t;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                if (fclk == kFrameSyms) {
-                    fclk = 0;
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = sh.f[i];
-                    const SyncResult r = sync_check(v);
-                    uint32_t flags = 0;
-                    bool parse = false, unlock = false;
-                    if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
-                    else if (sync_accept(r, true)) { flags |= M17_F_SYNC_OK; parse = true; ferr = 0; }
-                    else {
-                        ferr++;
-                        if (ferr > 5) { flags |= M17_F_LOST; unlock = true; }
-                        else parse = true;
-                    }
-                    if (parse && mode == 1) flags |= M17_F_PARSED;
-                    const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
-                    emit_record(crecs, rec_cap, nrec, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
-                    if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
-                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kFrameSyms;
-                        for (int q = lane; q < kFrameSyms; q += 64) fd[q] = sh.f[q];
-                        if (work && lane == 0) work[atomicAdd(nwork, 1)] = chan * rec_cap + nrec;
-                    }
-                    nrec++;
-                    if (unlock) {
-                        flock = 0;
-                        // reset_sync(): the next hunt windows must see zeros behind them
-                        if (lane < 8) sh.h[pos + lane] = 0.0f;
-                        if (lane < 8) cs.sync[lane] = 0.0f;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    }
-                }
-            } else {
-                // hunt: candidate j = pos+lane, window = m_sync after shifting symbol j in
-                const int j = pos + lane;
-                const bool cand = j < n;
-                const int jj = cand ? j : pos;
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = sh.h[jj + 1 + i];
-                const SyncResult r = sync_check(v);
-                const unsigned long long hit = __ballot(cand && sync_accept(r, false));
-                if (hit) {
-                    const int l = __ffsll((long long)hit) - 1;
-                    const int js = pos + l;
-                    // copy_sync(); m_fclk = 8; lock; m17_aos()
-                    if (lane < 8) { const float w = sh.h[js + 1 + lane]; sh.f[lane] = w; cs.sync[lane] = w; }
-                    fclk = 8; ferr = 0; flock = 1;
-                    const int ty = bcast_lane_i(r.type, l), vo = bcast_lane_i(r.votes, l);
-                    const float va = bcast_lane(r.variance, l);
-                    emit_record(crecs, rec_cap, nrec, (uint32_t)ty | ((uint32_t)vo << 8), M17_F_AOS, va,
-                                block_count, (uint32_t)js);
-                    nrec++;
-                    pos = js + 1;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                } else {
-                    pos = min(n, pos + 64);
-                }
-            }
-        }
-        // m_sync for the next block while hunting: last 8 entries of h
-        if (!flock) {
-            float keep = 0.0f;
-            if (lane < 8) keep = sh.h[n + lane];
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 8) { sh.h[lane] = keep; cs.sync[lane] = keep; }
-        }
-        block_count++;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-
-    // ---- store state
-    if (lane == 0) {
-        cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum; cs.dif = dif;
-        cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count;
-        cs.buff[0] = 0.0f;
-    }
-    if (lane < kTaps - 1) cs.buff[lane + 1] = sh.x[lane];
-    for (int q = lane; q < kFrameSyms; q += 64) cs.fsym[q] = sh.f[q];
-    if (counts && lane == 0) counts[chan] = nrec;
 }
 
 // ---------------------------------------------------------------------------

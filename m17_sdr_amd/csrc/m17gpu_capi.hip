@@ -3,7 +3,6 @@
 #include "m17_kernels.hip"
 #include "m17_sync_wg.hip"
 #include "m17_sync_wave.hip"
-#include "m17_sync_ch.hip"
 #include "m17_sync_grp.hip"
 #include "m17_sync_ring.hip"
 #include "m17_decode_chan.hip"
@@ -41,9 +40,8 @@ struct m17gpu_ctx {
                                              // 1 = workgroup per channel (16 lanes per frame + bookkeeping), 0 = work list built by the framer + k_lsf
     bool profiling = false;
     int fe_impl = 0;                         // 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block
-    int sync_impl = 4;                       // 4 = lane group per channel (default; with decode_impl 0 it runs as 2), 2 = wave per channel,
-                                             // 3 = controller + helper waves, 1 = workgroup per channel, 0 = first version
-    int allow_fast = 0;                      // multi-block fast windows in k_sync_frame_wg                       // 1 = workgroup per channel (default), 0 = wave per channel
+    int sync_impl = 4;                       // 4 = lane group per channel (default), 5 = same with a symbol ring, 2 = wave per channel
+                                             // (also what 4 / 5 run as under decode_impl 0)
     std::vector<hipEvent_t> ev_pool;         // 5 events per profiled call
     std::vector<int> ev_mode;                // mode of each profiled call
 };
@@ -155,30 +153,13 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms, ctx->d_fsym, b0, bcount)
         if (lpc == 64) LAUNCH_GRP(64); else if (lpc == 32) LAUNCH_GRP(32); else LAUNCH_GRP(16);
 #undef LAUNCH_GRP
-    } else if (ctx->sync_impl == 3)
-        hipLaunchKernelGGL(k_sync_frame_ch, dim3(ctx->C), dim3(64 * CH_WAVES), 0, st,
-                           disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
-                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
-                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
-                           ctx->d_fsym, wl, ctx->d_nwork);
-    else if (ctx->sync_impl == 2 || ctx->sync_impl == 4 || ctx->sync_impl == 5)
+    } else
+        // decode_impl 0 needs the framer-built work list, which only the wave-per-channel kernel has
         hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(ctx->C, SW_WAVES)), dim3(64 * SW_WAVES), 0, st,
                            disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
                            ctx->d_fsym, wl, ctx->d_nwork, b0, bcount);
-    else if (ctx->sync_impl == 1 || ext_lock >= 0)
-        hipLaunchKernelGGL(k_sync_frame_wg, dim3(ctx->C), dim3(WG_T), 0, st,
-                           disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
-                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
-                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
-                           ctx->d_fsym, wl, ctx->d_nwork, ctx->allow_fast);
-    else
-        hipLaunchKernelGGL(k_sync_frame, dim3(cdiv(ctx->C, SF_WAVES)), dim3(64 * SF_WAVES), 0, st,
-                           disc, offs, ctx->d_state, ctx->C, nblk, mode,
-                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
-                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
-                           ctx->d_fsym, wl, ctx->d_nwork);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -208,7 +189,6 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     if (!ctx) return fail(M17GPU_ERR_NOMEM, "m17gpu_create: out of host memory");
     ctx->device = device; ctx->C = n_channels; ctx->max_blocks = max_blocks;
     ctx->rec_cap_max = 2 * max_blocks + 2;
-    if (const char *e = std::getenv("M17GPU_FAST_WINDOWS")) ctx->allow_fast = std::atoi(e);
     if (const char *e = std::getenv("M17GPU_FE_IMPL")) ctx->fe_impl = std::atoi(e);
     if (const char *e = std::getenv("M17GPU_SYNC_IMPL")) ctx->sync_impl = std::atoi(e);
     if (const char *e = std::getenv("M17GPU_DECODE_IMPL")) ctx->decode_impl = std::atoi(e);
@@ -373,13 +353,12 @@ int m17gpu_selftest(m17gpu_ctx *ctx, unsigned *h_bad)
 }
 
 // Implementation selectors, for A/B measurements and so that every kernel variant stays
-// under the parity tests: "sync_impl" 0|1|2|3|4, "lanes_per_channel" 0|16|32|64, "fast_windows" 0|1,
+// under the parity tests: "sync_impl" 2|4|5, "lanes_per_channel" 0|16|32|64,
 // "fe_impl" 0|1|2, "decode_impl" 0|1|2.
 int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
     if (!std::strcmp(name, "sync_impl")) ctx->sync_impl = value;
-    else if (!std::strcmp(name, "fast_windows")) ctx->allow_fast = value;
     else if (!std::strcmp(name, "fe_impl")) ctx->fe_impl = value;
     else if (!std::strcmp(name, "decode_impl")) ctx->decode_impl = value;
     else if (!std::strcmp(name, "lanes_per_channel")) ctx->lanes_per_channel = value;
