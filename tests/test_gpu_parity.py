@@ -348,3 +348,50 @@ def test_gpu_signal_source_matches_host_generator(ebn0, cutoff):
     for c in range(C):
         assert recs[c, :counts[c]].tobytes() == ref["recs"][c, :counts[c]].tobytes()
     rx.close()
+
+
+@pytest.mark.parametrize("decode_impl", [1, 2])
+def test_stage_decode_frames_mixed_types_and_golay(decode_impl):
+    """m17gpu_decode_frames (the stateless part of m17_rx_parse) on a shuffled batch of link-setup,
+    stream and packet frames with noise, against the oracle frame by frame; m17gpu_golay_decode on
+    random 24-bit words."""
+    import ctypes as C
+    torch = _torch()
+    import m17_sdr_amd as m
+    L, O = m.lib(), oracle.L()
+    rng = np.random.default_rng(11)
+    lsf = np.zeros(30, np.uint8)
+    meta = np.zeros(14, np.uint8)
+    L.m17gen_build_lsf(0xFFFFFFFFFFFF, L.m17gen_encode_call(b"AB1CD    "), 5, meta.ctypes.data_as(C.c_void_p), lsf.ctypes.data_as(C.c_void_p))
+    n = 150
+    types = rng.integers(1, 4, size=n).astype(np.uint8)
+    sym = np.zeros((n, 192), np.float32)
+    level = np.array([1.0, 3.0, -1.0, -3.0], np.float32)
+    for i in range(n):
+        d = np.zeros(192, np.uint8)
+        pay = rng.integers(0, 256, size=25, dtype=np.uint8)
+        if types[i] == 1:
+            L.m17gen_lsf_frame_dibits(lsf.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p))
+        elif types[i] == 2:
+            L.m17gen_stream_frame_dibits(lsf.ctypes.data_as(C.c_void_p), i % 6, i, pay.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p))
+        else:
+            L.m17gen_packet_frame_dibits(pay.ctypes.data_as(C.c_void_p), 25, i & 1, i % 32, d.ctypes.data_as(C.c_void_p))
+        a = np.float32(rng.uniform(0.05, 2.0))
+        sym[i] = a * level[d & 3] + a * np.float32(rng.choice([0.0, 0.15, 0.6])) * rng.standard_normal(192).astype(np.float32)
+    rx = m.Receiver(4, 2)
+    rx.set_option("decode_impl", decode_impl)
+    got = rx.decode_frames(torch.from_numpy(sym).cuda(), torch.from_numpy(types).cuda()).cpu().numpy().view(oracle.REC_DTYPE).reshape(-1)
+    for i in range(n):
+        ch = oracle.Channels(1)
+        rec = np.zeros(1, oracle.REC_DTYPE)
+        O.m17o_rx_parse(ch.buf.ctypes.data_as(C.c_void_p), sym[i].ctypes.data_as(C.c_void_p), int(types[i]), rec.ctypes.data_as(C.c_void_p))
+        assert got[i]["type"] == types[i]
+        assert got[i]["data"].tobytes() == rec[0]["data"].tobytes(), (i, types[i])
+        assert got[i]["fn"] == rec[0]["fn"] and got[i]["golay_errs"] == rec[0]["golay_errs"], (i, types[i])
+    words = rng.integers(0, 1 << 24, size=5000, dtype=np.uint32)
+    g = rx.golay_decode(torch.from_numpy(words.view(np.int32)).cuda()).cpu().numpy().view(np.uint16)
+    for w, x in zip(words[:600], g[:600]):
+        od = C.c_uint16()
+        e = O.m17o_golay_decode(int(w), C.byref(od))
+        assert int(x) == (od.value | (e << 12))
+    rx.close()
