@@ -57,13 +57,16 @@ def make_input(args, rank, torch, rx):
     C, nblk = args.channels, args.blocks
     T = args.warmup + args.steps
     if args.gen == "gpu":
-        big = rx.gen_batch(nblk * T, n_stream_frames=40, ebn0_db=args.ebn0, first_channel=rank * C)["iq"]
+        # at most ~20 GB of distinct signal (plus as much again while it is cut into slabs): longer runs wrap
+        # around, i.e. one frame-phase break per pass over the slabs instead of one per step
+        Tg = max(1, min(T, int(20e9 // (C * nblk * 7680))))
+        big = rx.gen_batch(nblk * Tg, n_stream_frames=40, ebn0_db=args.ebn0, first_channel=rank * C)["iq"]
         torch.cuda.synchronize()
-        slabs = big.view(C, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4).contiguous()
+        slabs = big.view(C, Tg, nblk, 1920, 2).permute(1, 0, 2, 3, 4).contiguous()
         del big
         torch.cuda.empty_cache()
-        steps = [slabs[k] for k in range(T)]
-        return steps, {"iq": steps[args.warmup][:min(256, C)].cpu().numpy()}
+        steps = [slabs[k % Tg] for k in range(T)]
+        return steps, {"iq": steps[min(args.warmup, Tg - 1)][:min(256, C)].cpu().numpy()}
     uniq = min(args.unique, C)
     nthreads = max(1, min(16, (os.cpu_count() or 8) // max(1, args.gpus)))
     sig = m.generate_batch(uniq, nblk, n_stream_frames=40, ebn0_db=args.ebn0,
@@ -187,7 +190,7 @@ def main():
                                 "full chain incl. soft Viterbi + depuncture/deinterleave/Golay (BASELINE configs[2])"),
                    "channels_per_gpu": C, "blocks_per_step": nblk, "samples_per_block": 1920,
                    "realtime_channels": int(msym * 1e6 / 4800), "ebn0_db": args.ebn0,
-                   "signal_source": ("m17gpu_gen_batch (device), one continuous %.0f s stream per channel cut into steps" % (0.04 * nblk * (args.warmup + args.steps))
+                   "signal_source": ("m17gpu_gen_batch (device), one continuous stream per channel (up to %.0f s) cut into steps" % (0.04 * nblk * (args.warmup + args.steps))
                                      if args.gen == "gpu" else "m17gen_batch (host, tiled), the same slab every step"),
                    "parallelism": f"channel-sharded x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
