@@ -1,6 +1,6 @@
 import sys, subprocess, os, json
 cfgs = [(1024, 50), (4096, 25), (16384, 12)]
-variants = [("2", "0"), ("4", "64"), ("4", "32"), ("4", "16")]
+variants = [("4", "0")]
 for C, nblk in cfgs:
     for s, lpc in variants:
         for wl in ("frontend", "full"):
