@@ -178,6 +178,20 @@ int m17gpu_get_golay_tables(uint16_t *h_enc /* [4096] */, uint16_t *h_err /* [40
 int m17gpu_format_net_frame(uint16_t stream_id, const uint8_t lsf[30], uint16_t fn, const uint8_t payload[16],
                             uint64_t dst_override, uint8_t out[54]);
 
+/* LSF field extraction (parse_lsf m17_rx_parse.cpp:52-70 with m17_decode_call
+ * m17_bit_utils.cpp:209-226 and m17_upack_type :245-254): what the reference hands to
+ * gui_save_dest_address / gui_save_src_address / valid_lsf_received.  The base-40
+ * callsign has its first character least significant; 0xFFFFFFFFFFFF reads "BROADCAST". */
+typedef struct {
+    uint64_t dst, src;            /* 48-bit encoded addresses */
+    char     dst_call[10], src_call[10];
+    uint8_t  p_s, dt, et, est, can, reserved;     /* type word, packet/stream bit upward */
+    uint8_t  meta[14];
+    uint16_t crc;                 /* lsf[28..29]; crc_ok = CRC-16 over all 30 bytes is 0 */
+    uint8_t  crc_ok;
+} m17gpu_lsf_fields;
+int m17gpu_parse_lsf(const uint8_t lsf[30], m17gpu_lsf_fields *out);
+
 /* ---------------- synthetic signal source (host) ----------------
  * A restatement of the reference transmitter (framer m17_tx_routines.cpp:24-255,
  * 4-FSK modulator m17_modulate.cpp:22-86, 10 samples/symbol) used to produce

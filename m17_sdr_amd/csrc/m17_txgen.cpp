@@ -294,6 +294,43 @@ int m17gpu_format_net_frame(uint16_t stream_id, const uint8_t lsf[30], uint16_t 
     return 54;
 }
 
+static void decode_call(uint64_t word, char call[10])          // m17_bit_utils.cpp:209-226
+{
+    if (word == 0xFFFFFFFFFFFFull) { std::memcpy(call, "BROADCAST", 10); return; }
+    for (int i = 0; i < 9; ++i) {
+        const int ch = (int)(word % 40);
+        char o = ' ';
+        if (ch >= 1 && ch <= 26) o = (char)(ch + 'A' - 1);
+        else if (ch >= 27 && ch <= 36) o = (char)(ch + '0' - 27);
+        else if (ch == 37) o = '-';
+        else if (ch == 38) o = '/';
+        else if (ch == 39) o = '.';
+        call[i] = o;
+        word /= 40;
+    }
+    call[9] = 0;
+}
+
+int m17gpu_parse_lsf(const uint8_t lsf[30], m17gpu_lsf_fields *out)
+{
+    if (!lsf || !out) return M17GPU_ERR_ARG;
+    std::memset(out, 0, sizeof *out);
+    for (int i = 0; i < 6; ++i) { out->dst = (out->dst << 8) | lsf[i]; out->src = (out->src << 8) | lsf[6 + i]; }   // pack_8_to_48
+    decode_call(out->dst, out->dst_call);
+    decode_call(out->src, out->src_call);
+    const unsigned tw = ((unsigned)lsf[12] << 8) | lsf[13];                 // pack_8_to_16, m17_upack_type
+    out->reserved = (uint8_t)((tw >> 11) & 0x1F);
+    out->can = (uint8_t)((tw >> 7) & 0xF);
+    out->est = (uint8_t)((tw >> 5) & 0x3);
+    out->et = (uint8_t)((tw >> 3) & 0x3);
+    out->dt = (uint8_t)((tw >> 1) & 0x3);
+    out->p_s = (uint8_t)(tw & 1);
+    std::memcpy(out->meta, &lsf[14], 14);
+    out->crc = (uint16_t)(((unsigned)lsf[28] << 8) | lsf[29]);
+    out->crc_ok = m17::crc16(lsf, 30) == 0;
+    return M17GPU_OK;
+}
+
 static thread_local Modulator g_mod;
 
 int m17gen_modulate(const uint8_t *dibits, int n, int16_t *h_iq, int reset)

@@ -123,3 +123,34 @@ def test_net_frame_format():
     call = lib.m17gen_encode_call(b"M17-M17 A")
     lib.m17gpu_format_net_frame(1, oracle.vp(lsf), 0, oracle.vp(pl), call, oracle.vp(out))
     assert int.from_bytes(bytes(out[6:12]), "big") == call and oracle.L().m17o_crc(bytes(out), 54) == 0
+
+
+def test_parse_lsf_fields_against_survey_kats():
+    """SURVEY 8(c) callsign KATs through m17gpu_parse_lsf, cross-checked with the oracle's decoder."""
+    import ctypes as C
+    import numpy as np
+    from m17_sdr_amd import _lib
+    from tests import oracle
+    L = _lib.load()
+
+    class Fields(C.Structure):
+        _fields_ = [("dst", C.c_uint64), ("src", C.c_uint64), ("dst_call", C.c_char * 10), ("src_call", C.c_char * 10),
+                    ("p_s", C.c_uint8), ("dt", C.c_uint8), ("et", C.c_uint8), ("est", C.c_uint8), ("can", C.c_uint8),
+                    ("reserved", C.c_uint8), ("meta", C.c_uint8 * 14), ("crc", C.c_uint16), ("crc_ok", C.c_uint8)]
+
+    assert L.m17gen_encode_call(b"G4GUO/P  ") == 0x00102C8DA29F and L.m17gen_encode_call(b"AB1CD    ") == 0x0000009FDD51
+    lsf = np.zeros(30, np.uint8)
+    meta = np.arange(14, dtype=np.uint8)
+    tw = (3 << 7) | (2 << 1) | 1                       # CAN 3, voice, stream
+    L.m17gen_build_lsf(0xFFFFFFFFFFFF, 0x00102C8DA29F, tw, meta.ctypes.data_as(C.c_void_p), lsf.ctypes.data_as(C.c_void_p))
+    f = Fields()
+    assert L.m17gpu_parse_lsf(lsf.ctypes.data_as(C.c_void_p), C.byref(f)) == 0
+    assert f.dst == 0xFFFFFFFFFFFF and f.dst_call == b"BROADCAST"
+    assert f.src == 0x00102C8DA29F and f.src_call == b"G4GUO/P  "
+    assert (f.p_s, f.dt, f.et, f.est, f.can, f.reserved) == (1, 2, 0, 0, 3, 0)
+    assert bytes(f.meta) == meta.tobytes() and f.crc_ok == 1
+    buf = C.create_string_buffer(10)
+    oracle.L().m17o_decode_call(C.c_uint64(0x0000009FDD51), buf)
+    lsf[6:12] = [0, 0, 0, 0x9F, 0xDD, 0x51]
+    L.m17gpu_parse_lsf(lsf.ctypes.data_as(C.c_void_p), C.byref(f))
+    assert f.src_call == buf.value == b"AB1CD    " and f.crc_ok == 0
