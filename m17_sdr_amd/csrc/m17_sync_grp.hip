@@ -280,7 +280,16 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
         }
 
         // symbols out (optional)
-        if (syms) for (int q = gl; q < n; q += LPC) syms[sym_base + sym_total + q] = my.h[8 + q];
+        if (syms) {
+            // at most 193 symbols: a fixed number of predicated stores (the generic strided loop compiled to
+            // 169 instructions of 64-bit index arithmetic)
+            float *so = syms + sym_base + sym_total;
+#pragma unroll
+            for (int r = 0; r < (193 + LPC - 1) / LPC; ++r) {
+                const int q = gl + LPC * r;
+                if (q < n) so[q] = my.h[8 + q];
+            }
+        }
         if (nsyms && gl == 0) nsyms[(size_t)chan * nblk + b] = n;
         sym_total += n;
 
