@@ -1,24 +1,19 @@
-// m17_kernels.hip -- CDNA4 (gfx950) kernels of the batched M17 receive chain.
+// m17_kernels.hip -- CDNA4 (gfx950) kernels of the batched M17 receive chain, first of the
+// translation unit's parts (m17gpu_capi.hip includes them in order, one namespace).
 //
-// Data-parallel restatement of the reference's single-channel, file-static
-// receive path.  Four kernels per call:
+// Data-parallel restatement of the reference's single-channel, file-static receive path
+// (SURVEY.md section 8a).  What m17gpu_rx_blocks launches by default:
 //
-//   k_frontend    a3+a5+a6   int16 IQ -> limiter -> discriminator -> /5 -> DC sum
-//                 one LANE per (channel, block): the 1920-term DC sum is a strict
-//                 sequential fp32 chain, so each lane owns one chain; the IQ tile
-//                 is staged through LDS so HBM sees 160-byte row segments and the
-//                 per-lane reads are conflict-free ds_read_b128.
-//   k_sync_frame  a9+a11+a12 timing recovery + sync correlator + framer
-//                 one WAVE per channel, blocks in order: 64 lanes evaluate 64
-//                 consecutive symbol instants of the polyphase matched/derivative
-//                 FIR speculatively under the current phase; the vote counter is a
-//                 ballot/popcount prefix, the first threshold crossing truncates
-//                 the speculation.  Sync-word hunting correlates 64 window
-//                 positions at once.
-//   k_decode      a14..a24   demap, fused de-randomise/de-interleave/de-puncture
-//                 gather, Viterbi with one trellis state per lane (16 lanes per
-//                 frame, ds_bpermute butterflies), Golay, packers.
-//   k_lsf         a25 etc.   per-channel in-order LICH/LSF/packet bookkeeping.
+//   k_frontend_q      a3+a5+a6   int16 IQ -> limiter -> discriminator -> /5 -> DC sum      (this file)
+//                     16 (channel, block) rows per wave, 4 lanes per row; the 1920-term DC sum is a
+//                     strict sequential fp32 chain, one per row.  k_frontend: one lane per row.
+//   k_sync_frame_grp  a9+a11+a12 timing recovery + sync correlator + framer                (m17_sync_grp.hip)
+//   k_worklist, k_decode_quad    a14..a24 demap / gather / Viterbi / Golay / packers       (m17_decode_quad.hip)
+//   k_book_chan       a25 etc.   per-channel in-order LICH/LSF/packet bookkeeping          (m17_decode_*.hip)
+//
+// Also here: the exact-arithmetic helpers with their exhaustive self tests, the sync correlator
+// (sync_check, sync_accept), the 16-lanes-per-frame decoder (decode_frame16, k_decode, and the
+// stage kernels k_viterbi / k_demap / k_golay), k_lsf and k_reset.
 //
 // Numeric contract: IEEE binary32, no FMA contraction, no
 // re-association, correctly rounded sqrt/divide; the double-promoted
