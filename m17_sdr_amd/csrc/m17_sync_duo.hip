@@ -1,0 +1,308 @@
+// m17_sync_duo.hip -- k_sync_frame_duo: timing recovery and framer of one channel on TWO waves
+// of the same workgroup, decoupled by one block (64 lanes per channel; <= 2,048 channels).
+//
+// Reference: m17_rx_sync_samples (m17_rx_sync.cpp:77-99), m17_rx_sym (m17_rx_frame.cpp:126-177).
+//
+// Why: with 1,024 channels the lane-group kernel has exactly one wave per SIMD, a wave issues one
+// instruction per ~8 cycles whatever it does, and a SIMD can issue twice that -- half the issue
+// slots idle while every channel's blocks run strictly in order.  The only thing the timing loop
+// takes from the framer is the lock flag (threshold 80 / 10, m17_rx_sync.cpp:50 via m17_rx_lock()),
+// and that changes about twice per transmission.  So:
+//   timing wave : runs block b under the lock flag it last saw (after the framer of b-2), then
+//                 waits for the framer of b-1 -- normally long done -- and, only if the flag
+//                 differs, restores its five state variables and runs block b again.  It then
+//                 publishes the block's symbols (in the channel's LDS ring) and moves on.
+//   framer wave : one block behind: symbol stream out, frame sync checks, records, frame symbols.
+// Both waves are resident by construction (same workgroup), every wait is on a flag the other
+// wave sets without waiting for anything later, and both run exactly `bcount` blocks: no wait can
+// outlive the kernel.  Results are the serial results -- a misprediction is recomputed, not patched.
+#pragma clang fp contract(off)
+
+namespace m17dev {
+
+constexpr int kDuoRing = 1024;                 // 193 (block being written) + 193 + 192 (frame the framer may still read) < 1024
+
+struct DuoChan {                               // LDS of one channel
+    float x[kTaps - 1 + kDiscOut + 2];         // delay-line history (30) + this block's 384 inputs   (timing wave)
+    float H[kDuoRing];                         // symbol ring: timing wave writes, framer wave reads
+    int   nsym[4];                             // symbols of block b at [b & 3]
+    int   lock_after[4];                       // lock flag after the framer of block b at [b & 3]
+    int   tim_blk, frm_blk;                    // blocks published / framed since b0
+    int   pad[6];
+};
+
+__device__ __forceinline__ void duo_wait(const volatile int *flag, int need)
+{
+    while (*flag < need) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void duo_post(volatile int *flag, int value, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) *flag = value;
+}
+
+__global__ __launch_bounds__(512)
+void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
+                      const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
+                      ChanState *__restrict__ st, int C, int nblk, int mode,
+                      m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
+                      float *__restrict__ syms, int32_t *__restrict__ nsyms,
+                      float *__restrict__ fsym, int b0, int bcount)
+{
+    constexpr int LPC = 64;
+    __shared__ __attribute__((aligned(16))) float taps[kPhases * 64];      // (matched, derivative) pairs per branch
+    __shared__ __attribute__((aligned(16))) DuoChan chs[4];
+    const int wave = (int)(threadIdx.x >> 6), gl = lane_id();
+    const int w = wave & 3;
+    const bool is_framer = wave >= 4;
+    for (int q = (int)threadIdx.x; q < kPhases * 32; q += 512) {
+        taps[2 * q] = (&c_tab.mf[0][0])[q];
+        taps[2 * q + 1] = (&c_tab.md[0][0])[q];
+    }
+    if (threadIdx.x < 4) { chs[threadIdx.x].tim_blk = 0; chs[threadIdx.x].frm_blk = 0; }
+    __syncthreads();                                    // the only workgroup barrier
+    const int chan = (int)blockIdx.x * 4 + w;
+    if (chan >= C) return;                              // both waves of the channel leave together
+    DuoChan &my = chs[w];
+    ChanState &cs = st[chan];
+    const int bend = b0 + bcount;
+    volatile int *tim_blk = &my.tim_blk, *frm_blk = &my.frm_blk;
+
+    if (!is_framer) {
+        // =========================== timing wave ===========================
+        const unsigned long long incl = (gl == 63) ? ~0ull : ((2ull << gl) - 1ull);
+        int clk = cs.clk, thr = cs.thr, index = cs.index;
+        float sum = cs.sum, dif = cs.dif;
+        int known_lock = cs.flock;
+        int hp = 256;
+        for (int q = gl; q < kTaps - 1; q += LPC) my.x[q] = cs.buff[q + 1];
+        const float *dsrc = disc + (size_t)chan * nblk * kDiscOut;
+        const float *osrc = offs ? offs + (size_t)chan * nblk : nullptr;
+        {
+            const float off = osrc ? osrc[b0] : 0.0f;
+            for (int q = gl; q < kDiscOut; q += LPC) {
+                float v = dsrc[(size_t)b0 * kDiscOut + q];
+                if (osrc) v = v - off;                               // out[i] - offset (m17_dsp.cpp:217-219)
+                my.x[kTaps - 1 + q] = v;
+            }
+        }
+        wave_fence();
+        for (int b = b0; b < bend; ++b) {
+            // next block's input: loads issued now, committed at the end of the block
+            constexpr int PF = kDiscOut / LPC;
+            float pf[PF];
+            float noff = 0.0f;
+            if (b + 1 < bend) {
+                const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
+                noff = osrc ? osrc[b + 1] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < PF; ++r) pf[r] = nx[gl + LPC * r];
+            }
+            const int s_clk = clk, s_thr = thr, s_index = index;
+            const float s_sum = sum, s_dif = dif;
+            int lockv = known_lock, n = 0;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                // ---- timing recovery in rounds of 64 instants; x[i .. i+30] is the delay line at input i
+                const int thresh = lockv ? 80 : 10;
+                int p = 0, m_idx = 0;
+                float4 tp[16];                                        // 32 tap pairs of the current branch
+                int tap_index = -1;
+                while (p < kDiscOut) {
+                    if (clk == 1) {
+                        // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72)
+                        clk = 0;
+                        const float d0 = (sum < 0.0f) ? -dif : dif;
+                        if (d0 > 0.0f) thr++;
+                        if (d0 < 0.0f) thr--;
+                        if (thr > thresh) {
+                            index = (index + 1 == kPhases) ? 0 : index + 1; thr = 0;
+                            if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.H[(hp + m_idx) & (kDuoRing - 1)] = 0.0f; m_idx++; }
+                        }
+                        if (thr < -thresh) {
+                            thr = 0; index = (index == 0) ? kPhases - 1 : index - 1;
+                            if (index == kPhases - 1) { clk = 1; m_idx--; }
+                        }
+                        p++;
+                        continue;
+                    }
+                    if (tap_index != index) {
+                        const float4 *t4 = reinterpret_cast<const float4 *>(&taps[64 * index]);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) tp[q] = t4[q];
+                        tap_index = index;
+                    }
+                    const int rem = (kDiscOut - p + 1) >> 1;          // filter instants left in the block
+                    const int nv = rem < LPC ? rem : LPC;
+                    const v2f a = fir_pair(my.x + p + 2 * (gl < nv ? gl : 0), tp);
+                    const float s = a.x, d = a.y;
+                    const bool vote_ok = (gl < nv) && (p + 2 * gl + 1 < kDiscOut);
+                    const float dd = (s < 0.0f) ? -d : d;
+                    const unsigned long long um = __builtin_amdgcn_ballot_w64(vote_ok && dd > 0.0f);
+                    const unsigned long long dm = __builtin_amdgcn_ballot_w64(vote_ok && dd < 0.0f);
+                    const int tk = thr + (int)__popcll(um & incl) - (int)__popcll(dm & incl);
+                    const unsigned long long cr = __builtin_amdgcn_ballot_w64(vote_ok && (tk > thresh || tk < -thresh));
+                    const int kl = cr ? (int)__ffsll((long long)cr) - 1 : 0;
+                    const int naccept = cr ? kl + 1 : nv;
+                    if (gl < naccept && (m_idx + gl) >= 0) my.H[(hp + m_idx + gl) & (kDuoRing - 1)] = s;
+                    m_idx += naccept;
+                    sum = __shfl(s, naccept - 1, 64);
+                    dif = __shfl(d, naccept - 1, 64);
+                    if (cr) {
+                        const int ts = __shfl(tk, kl, 64);
+                        thr = 0; clk = 0;
+                        if (ts > thresh) {
+                            index = (index + 1 == kPhases) ? 0 : index + 1;
+                            if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.H[(hp + m_idx) & (kDuoRing - 1)] = 0.0f; m_idx++; }
+                        } else {
+                            index = (index == 0) ? kPhases - 1 : index - 1;
+                            if (index == kPhases - 1) { clk = 1; m_idx--; }
+                        }
+                        p = p + 2 * kl + 2;
+                    } else {
+                        thr += (int)__popcll(um) - (int)__popcll(dm);
+                        const int ilast = p + 2 * (nv - 1);
+                        if (ilast + 1 < kDiscOut) { clk = 0; p = ilast + 2; }
+                        else { clk = 1; p = kDiscOut; }
+                    }
+                }
+                n = m_idx > 0 ? m_idx : 0;
+                // ---- the lock flag this block should have seen: after the framer of block b-1
+                int actual = known_lock;
+                if (b > b0) {
+                    duo_wait(frm_blk, b - b0);
+                    actual = reinterpret_cast<volatile int *>(my.lock_after)[(b - 1) & 3];
+                }
+                if (actual == lockv) break;
+                lockv = actual;                                       // mispredicted (lock just changed): run the block again
+                clk = s_clk; thr = s_thr; index = s_index; sum = s_sum; dif = s_dif;
+            }
+            known_lock = lockv;
+            if (gl == 0) my.nsym[b & 3] = n;
+            duo_post(tim_blk, b - b0 + 1, gl);
+            hp += n;
+            // delay line: last 30 inputs; then the prefetched block moves in
+            {
+                const float keep_x = (gl < kTaps - 1) ? my.x[kDiscOut + gl] : 0.0f;
+                wave_fence();
+                if (gl < kTaps - 1) my.x[gl] = keep_x;
+                if (b + 1 < bend) {
+#pragma unroll
+                    for (int r = 0; r < PF; ++r)
+                        my.x[kTaps - 1 + gl + LPC * r] = osrc ? (pf[r] - noff) : pf[r];     // out[i] - offset
+                }
+            }
+            wave_fence();
+        }
+        if (gl == 0) { cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum; cs.dif = dif; cs.buff[0] = 0.0f; }
+        for (int q = gl; q < kTaps - 1; q += LPC) cs.buff[q + 1] = my.x[q];
+        return;
+    }
+
+    // =========================== framer wave ===========================
+    m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
+    if (!recs) rec_cap = 0;
+    int flock = cs.flock, fclk = cs.fclk, ferr = cs.ferr;
+    uint32_t block_count = cs.block_count;
+    int nrec = (b0 == 0) ? 0 : counts[chan];
+    int sym_total = (b0 == 0) ? 0 : cs.sym_total;
+    int hp = 256;
+    // m_f_sym[0 .. fclk) is the frame in progress: ring [hp - fclk, hp); m_sync is the last 8 symbols.
+    // Only positions below hp are written here: hp upward belongs to the timing wave from the start.
+    if (flock) { for (int q = gl; q < fclk; q += LPC) my.H[(hp - fclk + q) & (kDuoRing - 1)] = cs.fsym[q]; }
+    else if (gl < 8) my.H[(hp - 8 + gl) & (kDuoRing - 1)] = cs.sync[gl];
+    float *sym_out = syms ? syms + (size_t)chan * M17_SYM_STRIDE(nblk) + sym_total : nullptr;
+    wave_fence();
+    for (int b = b0; b < bend; ++b) {
+        duo_wait(tim_blk, b - b0 + 1);
+        const int n = reinterpret_cast<volatile int *>(my.nsym)[b & 3];
+        if (sym_out) {
+#pragma unroll
+            for (int r = 0; r < (193 + LPC - 1) / LPC; ++r) {
+                const int q = gl + LPC * r;
+                if (q < n) sym_out[q] = my.H[(hp + q) & (kDuoRing - 1)];
+            }
+            sym_out += n;
+        }
+        if (nsyms && gl == 0) nsyms[(size_t)chan * nblk + b] = n;
+        sym_total += n;
+        // ---- framer (m17_rx_frame.cpp:126-177) over ring symbols hp .. hp+n-1
+        int pos = 0;
+        while (pos < n) {
+            if (flock) {
+                const int cnt = min(kFrameSyms - fclk, n - pos);
+                fclk += cnt; pos += cnt;
+                if (fclk == kFrameSyms) {
+                    fclk = 0;
+                    const int fs = hp + pos - kFrameSyms;               // the frame sits in the ring, in place
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = my.H[(fs + i) & (kDuoRing - 1)];
+                    const SyncResult r = sync_check_grp<LPC>(v, gl, 0, 0);
+                    uint32_t flags = 0;
+                    bool parse = false, unlock = false;
+                    if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
+                    else if (sync_accept(r, true)) { flags |= M17_F_SYNC_OK; parse = true; ferr = 0; }
+                    else {
+                        ferr++;
+                        if (ferr > 5) { flags |= M17_F_LOST; unlock = true; }
+                        else parse = true;
+                    }
+                    if (parse && mode == 1) flags |= M17_F_PARSED;
+                    const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
+                    emit_record_grp(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
+                    if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
+                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kFrameSyms;
+                        for (int q = gl; q < kFrameSyms; q += LPC) fd[q] = my.H[(fs + q) & (kDuoRing - 1)];
+                    }
+                    nrec++;
+                    if (unlock) {
+                        flock = 0;
+                        // reset_sync(): the next hunt windows must see zeros behind them
+                        wave_fence();
+                        if (gl < 8) my.H[(hp + pos - 8 + gl) & (kDuoRing - 1)] = 0.0f;
+                        wave_fence();
+                    }
+                }
+            } else {
+                // hunt: candidate symbol j = pos+gl, window = ring [hp+j-7, hp+j]
+                const int jc = pos + gl;
+                const bool cand = jc < n;
+                const int jj = cand ? jc : pos;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = my.H[(hp + jj - 7 + i) & (kDuoRing - 1)];
+                SyncResult r; r.type = 0; r.votes = 8; r.variance = 1.0f;
+                if (cand && hunt_compatible(v)) r = sync_check(v);           // most windows are rejected by sign
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(cand && sync_accept(r, false));
+                if (hm) {
+                    const int l = (int)__ffsll((long long)hm) - 1;
+                    const int js = pos + l;
+                    // copy_sync(); m_fclk = 8; lock; m17_aos(): the window already is the head of the frame
+                    fclk = 8; ferr = 0; flock = 1;
+                    const int ty = __shfl(r.type, l, 64), vo = __shfl(r.votes, l, 64);
+                    const float va = __shfl(r.variance, l, 64);
+                    emit_record_grp(crecs, rec_cap, nrec, gl, (uint32_t)ty | ((uint32_t)vo << 8), M17_F_AOS, va,
+                                    block_count, (uint32_t)js);
+                    nrec++;
+                    pos = js + 1;
+                } else {
+                    pos = min(n, pos + LPC);
+                }
+            }
+        }
+        hp += n;
+        block_count++;
+        if (gl == 0) my.lock_after[b & 3] = flock;
+        duo_post(frm_blk, b - b0 + 1, gl);
+    }
+    // ---- store state in the reference's layout
+    if (gl == 0) {
+        cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count; cs.sym_total = sym_total;
+        if (counts) counts[chan] = nrec;
+    }
+    if (flock) { for (int q = gl; q < kFrameSyms; q += LPC) cs.fsym[q] = my.H[(hp - fclk + q) & (kDuoRing - 1)]; }
+    else if (gl < 8) cs.sync[gl] = my.H[(hp - 8 + gl) & (kDuoRing - 1)];
+}
+
+} // namespace m17dev

@@ -5,6 +5,7 @@
 #include "m17_sync_wave.hip"
 #include "m17_sync_grp.hip"
 #include "m17_sync_ring.hip"
+#include "m17_sync_duo.hip"
 #include "m17_decode_chan.hip"
 #include "m17_decode_quad.hip"
 #include "m17_pluto.hip"
@@ -143,10 +144,16 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
 {
     if (bcount < 0) bcount = nblk;
     int32_t *wl = ctx->decode_impl == 0 ? ctx->d_work : nullptr;      // the work list exists only for the legacy decode path
-    if ((ctx->sync_impl == 4 || ctx->sync_impl == 5) && ctx->decode_impl != 0) {
-        // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
-        int lpc = ctx->lanes_per_channel;
-        if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
+    // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
+    int lpc = ctx->lanes_per_channel;
+    if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
+    if (ctx->sync_impl == 6 && ctx->decode_impl != 0 && ext_lock < 0 && lpc == 64) {
+        // timing wave + framer wave per channel (m17_sync_duo.hip); other sizes / the lock-forced stage entry use 4
+        hipLaunchKernelGGL(k_sync_frame_duo, dim3(cdiv(ctx->C, 4)), dim3(512), 0, st,
+                           disc, offs, ctx->d_state, ctx->C, nblk, mode,
+                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
+                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms, ctx->d_fsym, b0, bcount);
+    } else if ((ctx->sync_impl >= 4 && ctx->sync_impl <= 6) && ctx->decode_impl != 0) {
 #define LAUNCH_GRP(L) hipLaunchKernelGGL((ctx->sync_impl == 5 ? k_sync_frame_ring<L> : k_sync_frame_grp<L>), dim3(cdiv(ctx->C, GrpCfg<L>::CPW)), dim3(256), 0, st, \
                            disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,                                  \
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,                        \
