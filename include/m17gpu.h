@@ -133,8 +133,9 @@ int m17gpu_decode_frames(m17gpu_ctx *ctx, const float *d_sym, const uint8_t *d_t
 int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_out, int n, void *stream);
 
 /* Kernel-variant selectors (A/B measurement, and so the parity tests cover every
- * variant): "sync_impl" 4 = lane group per channel (default), 5 = the same with one symbol ring
- * per channel, 2 = wave per channel; "lanes_per_channel" 0 = by channel count | 16 | 32 | 64
+ * variant): "sync_impl" 6 = timing wave + framer wave per channel, decoupled by one block, up to
+ * 1,024 channels and lane groups beyond (default), 4 = lane group per channel, 5 = the same with
+ * one symbol ring per channel, 2 = wave per channel; "lanes_per_channel" 0 = by channel count | 16 | 32 | 64
  * (sync_impl 4, 5);
  * "fe_impl" 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block;
  * "decode_impl" 2 = per-type work lists, four lanes per frame (DPP-quad Viterbi), wave per

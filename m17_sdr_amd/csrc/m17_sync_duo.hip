@@ -1,5 +1,5 @@
 // m17_sync_duo.hip -- k_sync_frame_duo: timing recovery and framer of one channel on TWO waves
-// of the same workgroup, decoupled by one block (64 lanes per channel; <= 2,048 channels).
+// of the same workgroup, decoupled by one block (64 lanes per channel; used up to 1,024 channels).
 //
 // Reference: m17_rx_sync_samples (m17_rx_sync.cpp:77-99), m17_rx_sym (m17_rx_frame.cpp:126-177).
 //

@@ -41,7 +41,8 @@ struct m17gpu_ctx {
                                              // 1 = workgroup per channel (16 lanes per frame + bookkeeping), 0 = work list built by the framer + k_lsf
     bool profiling = false;
     int fe_impl = 0;                         // 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block
-    int sync_impl = 4;                       // 4 = lane group per channel (default), 5 = same with a symbol ring, 2 = wave per channel
+    int sync_impl = 6;                       // 6 = timing wave + framer wave per channel up to 1,024 channels, lane groups beyond (default);
+                                             // 4 = lane group per channel, 5 = same with a symbol ring, 2 = wave per channel
                                              // (also what 4 / 5 run as under decode_impl 0)
     std::vector<hipEvent_t> ev_pool;         // 5 events per profiled call
     std::vector<int> ev_mode;                // mode of each profiled call
@@ -147,8 +148,10 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
     // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
     int lpc = ctx->lanes_per_channel;
     if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
-    if (ctx->sync_impl == 6 && ctx->decode_impl != 0 && ext_lock < 0 && lpc == 64) {
-        // timing wave + framer wave per channel (m17_sync_duo.hip); other sizes / the lock-forced stage entry use 4
+    if (ctx->sync_impl == 6 && ctx->decode_impl != 0 && ext_lock < 0 && lpc == 64 && ctx->C <= 1024) {
+        // timing wave + framer wave per channel (m17_sync_duo.hip): one 8-wave workgroup per CU.  Beyond 1,024
+        // channels a second workgroup per CU does not fit its registers and the lane-group kernel wins (2,048 x 50:
+        // 0.350 vs 0.288 ms); the lock-forced stage entry has no framer and uses the lane-group kernel too
         hipLaunchKernelGGL(k_sync_frame_duo, dim3(cdiv(ctx->C, 4)), dim3(512), 0, st,
                            disc, offs, ctx->d_state, ctx->C, nblk, mode,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
