@@ -69,6 +69,10 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
     const int bend = b0 + bcount;
     volatile int *tim_blk = &my.tim_blk, *frm_blk = &my.frm_blk;
 
+#ifdef M17_STAMPS
+    unsigned long long acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, last_ = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     if (!is_framer) {
         // =========================== timing wave ===========================
         const unsigned long long incl = (gl == 63) ? ~0ull : ((2ull << gl) - 1ull);
@@ -169,8 +173,10 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                 n = m_idx > 0 ? m_idx : 0;
                 // ---- the lock flag this block should have seen: after the framer of block b-1
                 int actual = known_lock;
+                STAMP(0);
                 if (b > b0) {
                     duo_wait(frm_blk, b - b0);
+                    STAMP(1);
                     actual = reinterpret_cast<volatile int *>(my.lock_after)[(b - 1) & 3];
                 }
                 if (actual == lockv) break;
@@ -194,6 +200,9 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
             }
             wave_fence();
         }
+#ifdef M17_STAMPS
+        if (chan == 0 && gl == 0) { g_stamps[0] = acc_[0]; g_stamps[1] = acc_[1]; }
+#endif
         if (gl == 0) { cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum; cs.dif = dif; cs.buff[0] = 0.0f; }
         for (int q = gl; q < kTaps - 1; q += LPC) cs.buff[q + 1] = my.x[q];
         return;
@@ -214,7 +223,9 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
     float *sym_out = syms ? syms + (size_t)chan * M17_SYM_STRIDE(nblk) + sym_total : nullptr;
     wave_fence();
     for (int b = b0; b < bend; ++b) {
+        STAMP(2);
         duo_wait(tim_blk, b - b0 + 1);
+        STAMP(3);
         const int n = reinterpret_cast<volatile int *>(my.nsym)[b & 3];
         if (sym_out) {
 #pragma unroll
@@ -296,6 +307,9 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
         if (gl == 0) my.lock_after[b & 3] = flock;
         duo_post(frm_blk, b - b0 + 1, gl);
     }
+#ifdef M17_STAMPS
+    if (chan == 0 && gl == 0) { g_stamps[2] = acc_[2]; g_stamps[3] = acc_[3]; }
+#endif
     // ---- store state in the reference's layout
     if (gl == 0) {
         cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count; cs.sym_total = sym_total;
