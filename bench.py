@@ -96,7 +96,7 @@ def cpu_baseline(args, sig):
     ch.rx_blocks(iq, mode=mode, want_syms=False, nthreads=cores)      # warm (tables, page faults)
     reps, t_used = 0, 0.0
     t0 = time.perf_counter()
-    while t_used < 1.5 and reps < 50:
+    while t_used < 1.5 and reps < 400:             # ~24 core-seconds on 16 threads
         ch.rx_blocks(iq, mode=mode, want_syms=False, nthreads=cores)
         reps += 1
         t_used = time.perf_counter() - t0
