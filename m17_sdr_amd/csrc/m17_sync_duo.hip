@@ -31,15 +31,21 @@ struct DuoChan {                               // LDS of one channel
     int   pad[6];
 };
 
-__device__ __forceinline__ void duo_wait(const volatile int *flag, int need)
+// Mailbox words are read and written as LDS words (ds_read / ds_write), not through generic pointers: a
+// volatile generic access compiles to flat_load ... sc0 sc1 + s_waitcnt vmcnt(0), several hundred cycles each.
+typedef __attribute__((address_space(3))) volatile int lds_vint;
+__device__ __forceinline__ int lds_peek(const int *p) { return *(const lds_vint *)p; }
+__device__ __forceinline__ void lds_poke(int *p, int v) { *(lds_vint *)p = v; }
+
+__device__ __forceinline__ void duo_wait(const int *flag, int need)
 {
-    while (*flag < need) __builtin_amdgcn_s_sleep(1);
+    while (lds_peek(flag) < need) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-__device__ __forceinline__ void duo_post(volatile int *flag, int value, int lane)
+__device__ __forceinline__ void duo_post(int *flag, int value, int lane)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) *flag = value;
+    if (lane == 0) lds_poke(flag, value);
 }
 
 __global__ __launch_bounds__(512)
@@ -67,7 +73,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
     DuoChan &my = chs[w];
     ChanState &cs = st[chan];
     const int bend = b0 + bcount;
-    volatile int *tim_blk = &my.tim_blk, *frm_blk = &my.frm_blk;
+    int *tim_blk = &my.tim_blk, *frm_blk = &my.frm_blk;
 
 #ifdef M17_STAMPS
     unsigned long long acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, last_ = __builtin_amdgcn_s_memtime();
@@ -177,7 +183,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                 if (b > b0) {
                     duo_wait(frm_blk, b - b0);
                     STAMP(1);
-                    actual = reinterpret_cast<volatile int *>(my.lock_after)[(b - 1) & 3];
+                    actual = lds_peek(&my.lock_after[(b - 1) & 3]);
                 }
                 if (actual == lockv) break;
                 lockv = actual;                                       // mispredicted (lock just changed): run the block again
@@ -226,7 +232,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
         STAMP(2);
         duo_wait(tim_blk, b - b0 + 1);
         STAMP(3);
-        const int n = reinterpret_cast<volatile int *>(my.nsym)[b & 3];
+        const int n = lds_peek(&my.nsym[b & 3]);
         if (sym_out) {
 #pragma unroll
             for (int r = 0; r < (193 + LPC - 1) / LPC; ++r) {
