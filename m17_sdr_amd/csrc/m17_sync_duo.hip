@@ -37,9 +37,12 @@ typedef __attribute__((address_space(3))) volatile int lds_vint;
 __device__ __forceinline__ int lds_peek(const int *p) { return *(const lds_vint *)p; }
 __device__ __forceinline__ void lds_poke(int *p, int v) { *(lds_vint *)p = v; }
 
+template <int SLEEP = 1>
 __device__ __forceinline__ void duo_wait(const int *flag, int need)
 {
-    while (lds_peek(flag) < need) __builtin_amdgcn_s_sleep(1);
+    // the poll shares the SIMD's issue slots with the other wave: the framer wave, which has ~2,700 cycles of
+    // slack per block, sleeps longer between looks than the timing wave
+    while (lds_peek(flag) < need) __builtin_amdgcn_s_sleep(SLEEP);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ void duo_post(int *flag, int value, int lane)
@@ -230,7 +233,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
     wave_fence();
     for (int b = b0; b < bend; ++b) {
         STAMP(2);
-        duo_wait(tim_blk, b - b0 + 1);
+        duo_wait<8>(tim_blk, b - b0 + 1);
         STAMP(3);
         const int n = lds_peek(&my.nsym[b & 3]);
         if (sym_out) {
