@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the batched M17 receive chain on N MI355X.
 
-A "step" is one pass of the hot path (m17gpu_rx_blocks) over one batch of
-synthetic IQ already resident in HBM: C channels x NBLK 1920-sample blocks per
-GPU.  Default workload = BASELINE.json configs[1]: 1,024 channels, front end
-only (discriminator + polyphase RRC timing recovery + sync correlator/framer).
-`--workload full` runs configs[2] (adds demap/Viterbi/Golay/LSF bookkeeping).
+A "step" is one pass of the hot path (m17gpu_rx_blocks) over one batch of synthetic IQ already
+resident in HBM: C channels x NBLK 1920-sample blocks per GPU.
 
-One JSON line is printed by rank 0 (contract in the task statement), carrying
-`roofline` (live HIP-event kernel durations against algorithmic bytes) and
-`cpu_baseline` (the CPU oracle timed on this host on a bounded sample).
+Default workload = the configuration BASELINE.json's metric is quoted on ("channels decoded in real
+time ... at 1/2/4/8 MI355X", configs[3]/[4]): FULL chain (discriminator, polyphase RRC timing
+recovery, sync correlator/framer, demap, de-randomise/de-interleave/de-puncture, soft Viterbi,
+Golay, LICH/LSF bookkeeping) at 16,384 channels per GPU.  The FIR-stage figure of configs[1]
+(1,024 channels, front end only) rides along as the nested "fir_stage" object so that north_star's
+40%-of-HBM target on that stage stays visible in the same line.
+
+`python bench.py --gpus N` starts the N ranks itself (one process per GPU, RCCL), unless it is
+already running as a rank of an external launcher (WORLD_SIZE set, e.g. torch.distributed.run).
+The parent process never touches the GPU.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (live HIP-event
+kernel durations on the launch stream against algorithmic bytes), `cpu_baseline` (the CPU oracle
+timed on this host on a bounded sample, N=1 only), `fir_stage` (N=1 only) and, for N>1, the
+separately timed RCCL fan-out legs `fanout_ms` / `gather_ms` (compute-only `value` and
+the with-fan-out figure are both reported).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,95 +37,231 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_FRONT = 7680 + 768              # IQ in + symbols out per channel-block
 BYTES_FULL = 7680 + 64                # IQ in + 64-byte record out
+KNAMES = ["k_frontend", "k_sync_frame", "k_worklist+k_decode", "k_bookkeeping"]
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
-    ap.add_argument("--blocks", type=int, default=50, help="1920-sample blocks per channel per step (2 s)")
-    ap.add_argument("--workload", choices=["frontend", "full"], default="frontend")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--channels", type=int, default=None, help="channels per GPU (default 16384 full / 1024 frontend)")
+    ap.add_argument("--blocks", type=int, default=None, help="1920-sample blocks per channel per step (default 12 full / 50 frontend)")
+    ap.add_argument("--workload", choices=["frontend", "full"], default="full")
     ap.add_argument("--ebn0", type=float, default=200.0, help="AWGN level of the synthetic IQ (>=100: none)")
     ap.add_argument("--unique", type=int, default=256, help="host generator: distinct generated channels (tiled to --channels)")
     ap.add_argument("--gen", choices=["gpu", "host"], default="gpu",
                     help="signal source: m17gpu_gen_batch on the device (every channel distinct) or the host generator")
+    ap.add_argument("--signal-gb", type=float, default=40.0, help="distinct signal kept in HBM per GPU before the stream wraps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fir-stage", action="store_true", help="skip the nested configs[1] FIR-stage measurement")
+    ap.add_argument("--no-fanout", action="store_true", help="N>1: skip the separately timed RCCL scatter/gather legs")
     ap.add_argument("--no-syms", action="store_true", help="front end: do not write the symbol stream")
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.channels is None:
+        args.channels = 16384 if args.workload == "full" else 1024
+    if args.blocks is None:
+        args.blocks = 12 if args.workload == "full" else 50
+    return args
 
 
-def make_input(args, rank, torch, rx):
+# ------------------------------------------------------------------------------------------------
+# parent: start one process per GPU (never touches HIP itself)
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        sys.stdout.write(out0 or "")
+        return next(rc for rc in rcs if rc) or 1
+    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if not line:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        return 1
+    print(line[-1], flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------
+def make_input(args, rank, torch, rx, C, nblk, T):
     """Synthetic IQ for this rank's channel shard, resident in HBM before the timed region.
-    Default: ONE continuous signal per channel, (warmup + steps) x blocks long, made on the device
-    by m17gpu_gen_batch (every channel distinct, seeded by global channel id) and
-    cut into per-step slabs [step][C][blocks] -- each step receives the next 2 s of every
-    channel, as a live receiver would, instead of the same 2 s again (which breaks the frame
-    phase at every step boundary and sends the framer hunting).  --gen host: the host generator,
-    tiled to C channels, the same slab every step.
+    Default: ONE continuous signal per channel made on the device by m17gpu_gen_batch (SURVEY 8f-1,
+    every channel distinct, seeded by global channel id: carrier, preambles, link setup frame, 40
+    stream frames, EOT, repeating) and cut into per-step slabs -- each step receives the next
+    nblk x 40 ms of every channel, as a live receiver would.  At most --signal-gb of distinct signal is
+    kept; longer runs wrap around (one frame-phase break per pass, like a transmission cut short).
+    --gen host: the host generator, tiled to C channels, the same slab every step.
     Returns (list of per-step device tensors, host copy of <= 256 channels of the first timed slab)."""
     import m17_sdr_amd as m
-    C, nblk = args.channels, args.blocks
-    T = args.warmup + args.steps
     if args.gen == "gpu":
-        # at most ~20 GB of distinct signal (plus as much again while it is cut into slabs): longer runs wrap
-        # around, i.e. one frame-phase break per pass over the slabs instead of one per step
-        Tg = max(1, min(T, int(20e9 // (C * nblk * 7680))))
+        Tg = max(1, min(T, int(args.signal_gb * 1e9 // (C * nblk * 7680))))
+        # the generator writes one stream per channel [C][nblk*Tg]; the C-ABI takes [C][nblk] per step, so the
+        # stream is re-laid out once as [step][C][nblk] (peak 2 x the signal; 288 GB of HBM make that a non-issue)
         big = rx.gen_batch(nblk * Tg, n_stream_frames=40, ebn0_db=args.ebn0, first_channel=rank * C)["iq"]
-        torch.cuda.synchronize()
-        slabs = big.view(C, Tg, nblk, 1920, 2).permute(1, 0, 2, 3, 4).contiguous()
+        torch.cuda.synchronize(rx.device)
+        slabs = torch.empty((Tg, C, nblk, 1920, 2), dtype=torch.int16, device=big.device)
+        slabs.copy_(big.view(C, Tg, nblk, 1920, 2).permute(1, 0, 2, 3, 4))
         del big
+        torch.cuda.synchronize(rx.device)
         torch.cuda.empty_cache()
         steps = [slabs[k % Tg] for k in range(T)]
-        return steps, {"iq": steps[min(args.warmup, Tg - 1)][:min(256, C)].cpu().numpy()}
+        w = min(args.warmup, Tg - 1)
+        return steps, {"iq": steps[w][:min(256, C)].cpu().numpy()}, Tg
     uniq = min(args.unique, C)
     nthreads = max(1, min(16, (os.cpu_count() or 8) // max(1, args.gpus)))
     sig = m.generate_batch(uniq, nblk, n_stream_frames=40, ebn0_db=args.ebn0,
                            first_channel=rank * C, nthreads=nthreads)
     host = torch.from_numpy(sig["iq"])
-    dev = torch.empty((C, nblk, 1920, 2), dtype=torch.int16, device="cuda")
+    dev = torch.empty((C, nblk, 1920, 2), dtype=torch.int16, device=f"cuda:{rx.device}")
     for c0 in range(0, C, uniq):
         n = min(uniq, C - c0)
         dev[c0:c0 + n].copy_(host[:n], non_blocking=False)
-    return [dev] * T, sig
+    return [dev] * T, sig, 1
 
 
-def cpu_baseline(args, sig):
-    """The CPU oracle (port of the reference path) on a bounded sample of the
-    same workload, all host threads, same run."""
+def cpu_baseline(mode, sig):
+    """The CPU oracle (port of the reference path) on a bounded sample of the same workload, all host
+    threads of this job's share, same run."""
     from tests import oracle
-    # the GPU box gives one GPU's job a share of 16 host threads (see task notes)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))
-    mode = 0 if args.workload == "frontend" else 1
+    cores = max(1, min(avail, 16))          # the GPU box gives one GPU's job a share of 16 host threads
     nch = sig["iq"].shape[0]
     iq = np.ascontiguousarray(sig["iq"][:nch])
     ch = oracle.Channels(nch)
     ch.rx_blocks(iq, mode=mode, want_syms=False, nthreads=cores)      # warm (tables, page faults)
     reps, t_used = 0, 0.0
     t0 = time.perf_counter()
-    while t_used < 1.5 and reps < 400:             # ~24 core-seconds on 16 threads
+    while t_used < 1.5 and reps < 2000:            # ~24 core-seconds on 16 threads
         ch.rx_blocks(iq, mode=mode, want_syms=False, nthreads=cores)
         reps += 1
         t_used = time.perf_counter() - t0
     syms = nch * iq.shape[1] * 192 * reps
-    # single-thread figure for comparison with SURVEY's 47.8 us/block
-    ch1 = oracle.Channels(1)
+    ch1 = oracle.Channels(1)                        # single-thread figure, to set beside SURVEY's 47.8 us/block
     t1 = time.perf_counter()
-    ch1.rx_blocks(iq[:1], mode=mode, want_syms=False, nthreads=1)
-    us_blk = (time.perf_counter() - t1) / iq.shape[1] * 1e6
+    for _ in range(8):
+        ch1.rx_blocks(iq[:1], mode=mode, want_syms=False, nthreads=1)
+    us_blk = (time.perf_counter() - t1) / (8 * iq.shape[1]) * 1e6
     return {"value": round(syms / t_used / 1e6, 3), "unit": "Msym/s", "cores": cores, "kind": "port",
             "sample": f"{nch} channels x {iq.shape[1]} blocks x {reps} passes of the same synthetic IQ, "
-                      f"OpenMP over channels ({t_used:.2f} s wall); 1 thread: {us_blk:.1f} us/block",
+                      f"{'full chain' if mode == 1 else 'front end'}, OpenMP over channels ({t_used:.2f} s wall); "
+                      f"1 thread: {us_blk:.1f} us/block",
             "realtime_channels": int(syms / t_used / 4800)}
 
 
-def main():
-    args = parse_args()
+def load_traffic(key):
+    """HBM-side bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE doubled, WRITE_SIZE as is:
+    MI355X_MICROARCH.md, HBM section).  Measured offline with rocprofv3 --pmc (it cannot run inside this process);
+    null when no pass exists for this exact workload key."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(path))
+        ent = tj.get(key)
+        if isinstance(ent, dict):
+            return ent.get("bytes"), ent.get("source")
+        return ent, "profiles/traffic.json"
+    except Exception:
+        return None, None
+
+
+def roofline_obj(kms, ncalls, mode, cb_per_launch, key):
+    per_unit = BYTES_FRONT if mode == 0 else BYTES_FULL
+    used = [i for i in range(4) if kms[i] > 0.002]
+    t_path_ms = sum(kms[i] for i in used)
+    dom = max(used, key=lambda i: kms[i]) if used else 0
+    achieved = per_unit * cb_per_launch / (t_path_ms * 1e-3) / 1e9 if t_path_ms > 0 else 0.0
+    traffic, tsrc = load_traffic(key)
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
+            "kernel": "+".join(KNAMES[i] for i in used), "dominant": KNAMES[dom],
+            "algorithmic_bytes_per_channel_block": per_unit, "channel_blocks_per_launch": cb_per_launch,
+            "avg_ms": {KNAMES[i]: round(kms[i], 4) for i in used}, "kernel_sum_ms": round(t_path_ms, 4),
+            "calls_timed": ncalls}
+
+
+def fir_stage(args, torch, device):
+    """BASELINE configs[1] in the same run: 1,024 channels x 50 blocks, front end only (limiter /
+    discriminator + polyphase RRC timing recovery + sync correlator), one continuous stream per channel."""
+    import m17_sdr_amd as m
+    C, nblk, steps, warm = 1024, 50, 30, 3
+    rx = m.Receiver(C, nblk, device=device)
+    T = steps + warm
+    big = rx.gen_batch(nblk * T, n_stream_frames=40, ebn0_db=200.0)["iq"]
+    torch.cuda.synchronize(device)
+    slabs = big.view(C, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4).contiguous()
+    del big
+    out = rx.alloc_outputs(nblk, want_syms=True)
+    for k in range(warm):
+        rx.rx_blocks(slabs[k], 0, out)
+    torch.cuda.synchronize(device)
+    rx.set_profiling(True)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        rx.rx_blocks(slabs[warm + k], 0, out)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    rx.set_profiling(False)
+    kms, ncalls = rx.kernel_ms()
+    rx.close()
+    del slabs
+    torch.cuda.empty_cache()
+    ro = roofline_obj(kms, ncalls, 0, C * nblk, f"frontend:{C}x{nblk}")
+    return {"workload": "BASELINE configs[1]: 1,024 channels x 50 blocks, RRC FIR + timing recovery + sync correlator only",
+            "ms": round(dt / steps * 1e3, 4), "value": round(C * nblk * 192 * steps / dt / 1e6, 3), "unit": "Msym/s",
+            "frac": ro["frac"], "achieved": ro["achieved"], "traffic": ro["traffic"], "avg_ms": ro["avg_ms"],
+            "kernel_sum_ms": ro["kernel_sum_ms"], "algorithmic_bytes_per_channel_block": BYTES_FRONT,
+            "channel_blocks_per_launch": C * nblk, "steps": steps, "target_frac": 0.40}
+
+
+def fanout_legs(args, torch, dist, rx, out, iq_step, world, rank, backend, C, nblk, mode):
+    """SURVEY 8(e) "with fan-out": rank 0 holds the IQ of all world x C channels of one step and fans it out to the
+    owning ranks point to point (shard.scatter_iq: one send per peer, xGMI is a full mesh); every rank runs the step;
+    the 64-byte records come back to rank 0 (shard.gather_records).  RCCL moves device tensors; under the gloo
+    rehearsal backend the same calls stage through host memory.  Timed apart from the compute-only region."""
+    from m17_sdr_amd import shard
+    dev = torch.device("cuda", rx.device)
+    total = world * C
+    full = None
+    if rank == 0:
+        full = iq_step.repeat(world, 1, 1, 1) if world > 1 else iq_step         # content is irrelevant to the transfer
+    reps = 5
+    t_sc, t_cp, t_ga = [], [], []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize(dev); dist.barrier(); t0 = time.perf_counter()
+        mine = shard.scatter_iq(full, total, nblk, src=0, device=dev)
+        torch.cuda.synchronize(dev); dist.barrier(); t1 = time.perf_counter()
+        rx.rx_blocks(mine, mode, out)
+        torch.cuda.synchronize(dev); dist.barrier(); t2 = time.perf_counter()
+        shard.gather_records(out["recs"], out["counts"], dst=0)
+        torch.cuda.synchronize(dev); dist.barrier(); t3 = time.perf_counter()
+        t_sc.append(t1 - t0); t_cp.append(t2 - t1); t_ga.append(t3 - t2)
+    vals = torch.tensor([sum(t_sc[1:]) / reps, sum(t_cp[1:]) / reps, sum(t_ga[1:]) / reps], dtype=torch.float64,
+                        device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+    sc, cp, ga = (float(v) * 1e3 for v in vals.tolist())
+    return {"fanout_ms": round(sc, 4), "gather_ms": round(ga, 4), "compute_ms_in_this_leg": round(cp, 4),
+            "iq_bytes_per_peer": C * nblk * 7680, "records_bytes_per_rank": int(out["recs"].numel()),
+            "scatter_GBps_from_root": round((world - 1) * C * nblk * 7680 / (sc * 1e-3) / 1e9, 2) if world > 1 and sc > 0 else None,
+            "reps": reps, "transport": "RCCL point-to-point send/recv + gather" if backend == "nccl" else f"{backend} (rehearsal, staged through host)"}
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
     import m17_sdr_amd as m
@@ -123,9 +271,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
-    local = local % max(1, torch.cuda.device_count())      # rehearsal: several ranks on one card
-    torch.cuda.set_device(local)
+    ndev = max(1, torch.cuda.device_count())
     backend = os.environ.get("M17_BENCH_BACKEND", "nccl")   # "gloo" to rehearse the N>1 path on a 1-GPU box
+    if world > ndev and backend == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, {ndev} visible (M17_BENCH_BACKEND=gloo rehearses on fewer)")
+    local = local % ndev                                    # rehearsal: several ranks on one card
+    torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -135,8 +286,9 @@ def main():
 
     C, nblk = args.channels, args.blocks
     mode = 0 if args.workload == "frontend" else 1
+    T = args.warmup + args.steps
     rx = m.Receiver(C, nblk, device=local)
-    iq, sig = make_input(args, rank, torch, rx)
+    iq, sig, Tg = make_input(args, rank, torch, rx, C, nblk, T)
     out = rx.alloc_outputs(nblk, want_syms=(mode == 0 and not args.no_syms))
 
     def barrier():
@@ -162,56 +314,64 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    fan = None
+    if world > 1 and not args.no_fanout:
+        fan = fanout_legs(args, torch, dist, rx, out, iq[args.warmup % len(iq)], world, rank, backend, C, nblk, mode)
+
     syms = world * C * nblk * 192 * args.steps
     msym = syms / dt / 1e6
-    cb_per_launch = C * nblk
-    per_unit = BYTES_FRONT if mode == 0 else BYTES_FULL
-    names = ["k_frontend", "k_sync_frame", "k_worklist+k_decode", "k_bookkeeping"]
-    used = [i for i in range(4) if kms[i] > 0.002]
-    t_path_ms = sum(kms[i] for i in used)
-    dom = max(used, key=lambda i: kms[i]) if used else 0
-    achieved = per_unit * cb_per_launch / (t_path_ms * 1e-3) / 1e9 if t_path_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = f"{args.workload}:{C}x{nblk}"
-            traffic = tj.get(key)
-        except Exception:
-            traffic = None
+    ms_step = dt / args.steps * 1e3
+    wl = ("full chain incl. soft Viterbi + depuncture/deinterleave/Golay + LICH/LSF bookkeeping, %s channels per GPU "
+          "(BASELINE configs[3]/[4] per-GPU size; configs[2] at 1,024)" % f"{C:,}") if mode == 1 else \
+         ("front end: limiter/discriminator + polyphase RRC timing recovery + sync correlator, %s channels per GPU "
+          "(BASELINE configs[1] at 1,024)" % f"{C:,}")
     line = {
-        "metric": "M17 symbols demodulated per second (real-time 48 kHz channels = value*1e6/4800)",
+        "metric": "M17 symbols demodulated + decoded per second (real-time 48 kHz channels = value*1e6/4800)",
         "value": round(msym, 3), "unit": "Msym/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("1,024-channel-class front end: limiter/discriminator + polyphase RRC timing "
-                                "recovery + sync correlator (BASELINE configs[1])" if mode == 0 else
-                                "full chain incl. soft Viterbi + depuncture/deinterleave/Golay (BASELINE configs[2])"),
-                   "channels_per_gpu": C, "blocks_per_step": nblk, "samples_per_block": 1920,
-                   "realtime_channels": int(msym * 1e6 / 4800), "ebn0_db": args.ebn0,
-                   "signal_source": ("m17gpu_gen_batch (device), one continuous stream per channel (up to %.0f s) cut into steps" % (0.04 * nblk * (args.warmup + args.steps))
+        "config": {"workload": wl, "mode": "full" if mode == 1 else "frontend",
+                   "channels_per_gpu": C, "channels_total": world * C, "blocks_per_step": nblk, "samples_per_block": 1920,
+                   "realtime_channels": int(msym * 1e6 / 4800), "realtime_channels_per_gpu": int(msym * 1e6 / 4800 / world),
+                   "ebn0_db": args.ebn0,
+                   "signal_source": ("m17gpu_gen_batch (device), one continuous stream per channel, %d distinct steps "
+                                     "(%.1f s) cut into %d-block steps%s" % (Tg, 0.04 * nblk * Tg, nblk, ", wrapping" if Tg < T else "")
                                      if args.gen == "gpu" else "m17gen_batch (host, tiled), the same slab every step"),
-                   "parallelism": f"channel-sharded x{world}, no data-path collective"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "kernel": "+".join(names[i] for i in used),
-                     "dominant": names[dom],
-                     "algorithmic_bytes_per_channel_block": per_unit,
-                     "channel_blocks_per_launch": cb_per_launch,
-                     "avg_ms": {names[i]: round(kms[i], 4) for i in used},
-                     "calls_timed": ncalls},
+                   "parallelism": f"channel-sharded x{world}, one process per GPU, no data-path collective in the timed region"},
+        "roofline": roofline_obj(kms, ncalls, mode, C * nblk, f"{args.workload}:{C}x{nblk}"),
     }
+    if fan is not None:
+        line["fanout"] = fan
+        wf = ms_step + fan["fanout_ms"] + fan["gather_ms"]
+        line["with_fanout"] = {"ms_per_step": round(wf, 4), "value": round(world * C * nblk * 192 / (wf * 1e-3) / 1e6, 3),
+                               "unit": "Msym/s", "note": "compute step + RCCL scatter of the IQ from rank 0 + gather of the records, not overlapped"}
     if rank == 0:
+        rx.close()
+        del iq
+        torch.cuda.empty_cache()
+        if world == 1 and not args.no_fir_stage and mode == 1:
+            line["fir_stage"] = fir_stage(args, torch, local)
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args, sig)
+            line["cpu_baseline"] = cpu_baseline(mode, sig)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    rx.close()
+    else:
+        rx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)           # before anything touches the GPU
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.stderr.write("bench.py: --gpus disagrees with WORLD_SIZE; using WORLD_SIZE\n")
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -9,8 +9,9 @@
  * channels in HBM and every entry point processes all of them in one launch.
  *
  * Pointer convention: arguments named d_* are DEVICE pointers (HBM, e.g. from
- * hipMalloc or torch.Tensor.data_ptr()); h_* are host pointers.  `stream` is a
- * hipStream_t passed as void* (NULL = default stream).  All calls are
+ * hipMalloc or torch.Tensor.data_ptr()) on the context's device; h_* are host pointers.
+ * `stream` is a hipStream_t of that device passed as void* (NULL = default stream).  Every
+ * entry point selects the context's device for its own duration and restores the caller's.  All calls are
  * asynchronous on `stream` unless stated.  Return value: 0 = ok, <0 = error
  * (m17gpu_last_error() gives the text).  There is NO CPU fallback: without a
  * HIP device every compute entry point fails with M17GPU_ERR_NO_DEVICE.
@@ -89,8 +90,11 @@ int  m17gpu_channels(const m17gpu_ctx *ctx);
  *                correlator/framer; records carry sync fields only)
  *            1 = full chain (+ demap, de-randomise, de-interleave, de-puncture,
  *                Viterbi, Golay, LICH/LSF bookkeeping)
- *   d_recs   [C][rec_cap] records, d_counts [C] number of events per channel
- *            (events beyond rec_cap are counted, not stored)
+ *   d_recs   [C][rec_cap] records, d_counts [C] number of events per channel.
+ *            mode 0: events beyond rec_cap are counted, not stored.
+ *            mode 1: 2*nblk+2 <= rec_cap <= 2*max_blocks+2 is required (M17GPU_ERR_ARG otherwise):
+ *            a block yields at most two events on average, so no event is ever dropped and every
+ *            frame reaches the LICH / counter / packet bookkeeping, as in the reference.
  *   d_syms   optional [C][M17GPU_SYM_STRIDE(nblk)] recovered symbols
  *            (m17_rx_sync_samples output), d_nsyms optional [C][nblk] counts */
 int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
@@ -116,7 +120,9 @@ int m17gpu_sync_frame(m17gpu_ctx *ctx, const float *d_disc, int nblk,
 int m17gpu_pluto_decimate(m17gpu_ctx *ctx, const int16_t *d_in, int n_in, int16_t *d_out, void *stream);
 /* m17_rx_sync_samples alone (m17_rx_sync.cpp:77-99): timing recovery with the lock
  * flag of an EXTERNAL framer (what m17_rx_lock() returns, m17_rx_frame.cpp:187),
- * the same flag for every channel and block of the call.  Framer state untouched. */
+ * the same flag for every channel and block of the call.  Only the timing state (m_buff, m_clk,
+ * m_thr, m_index, sum, dif) advances; the context's framer state, hunt window, block counter and
+ * record counts are untouched. */
 int m17gpu_sync_samples(m17gpu_ctx *ctx, const float *d_disc, int nblk, int lock,
                         float *d_syms, int32_t *d_nsyms, void *stream);
 /* m17_viterbi_decode (m17_conv.cpp:148-168) on n independent soft-bit vectors:
@@ -132,15 +138,15 @@ int m17gpu_decode_frames(m17gpu_ctx *ctx, const float *d_sym, const uint8_t *d_t
 /* m_17_golay_decode (m17_golay.cpp:103-116) on n 24-bit words: d_out[i] = data | weight<<12 */
 int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_out, int n, void *stream);
 
-/* Kernel-variant selectors (A/B measurement, and so the parity tests cover every
- * variant): "sync_impl" 6 = timing wave + framer wave per channel, decoupled by one block, up to
- * 1,024 channels and lane groups beyond (default), 4 = lane group per channel, 5 = the same with
- * one symbol ring per channel, 2 = wave per channel; "lanes_per_channel" 0 = by channel count | 16 | 32 | 64
- * (sync_impl 4, 5);
- * "fe_impl" 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block;
- * "decode_impl" 2 = per-type work lists, four lanes per frame (DPP-quad Viterbi), wave per
- * channel for the in-order bookkeeping (default); 1 = workgroup per channel, 16 lanes per
- * frame; 0 = work list built by the framer + separate LSF pass (sync_impl 4 then runs as 2). */
+/* Kernel-variant selectors (A/B measurement, and so the parity tests cover every variant).
+ * Every accepted value selects a kernel held to bit-exact parity; anything else returns
+ * M17GPU_ERR_ARG:
+ *   "sync_impl"          6 = timing wave + framer wave per channel, decoupled by one block, up to
+ *                            1,024 channels and lane groups beyond (default); 4 = lane group per
+ *                            channel at every size
+ *   "lanes_per_channel"  0 = by channel count (default) | 16 | 32 | 64 (lane-group kernel)
+ *   "fe_impl"            0 = by size (default), 1 = lane per channel-block, 2 = four lanes per
+ *                            channel-block */
 int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value);
 
 /* ---------------- measurement hooks ---------------- */
@@ -169,6 +175,13 @@ int m17gpu_get_lock(m17gpu_ctx *ctx, uint8_t *h_lock /* [C] */);
 /* host copies of the uploaded tables, for inspection / tests */
 int m17gpu_get_taps(float *h_mf /* [40][31] */, float *h_md /* [40][31] */);
 int m17gpu_get_golay_tables(uint16_t *h_enc /* [4096] */, uint16_t *h_err /* [4096] */);
+/* The literal constants the library is built from, by name (host only, no device needed); returns
+ * the number of bytes written or M17GPU_ERR_ARG.  "sframe" float[6][8] (m17_rx_frame.cpp:5-12),
+ * "derand_bits" u8[368] (m17_correlate.cpp:3-7,35-42), "golay_rows" u16[12] (m17_golay.cpp:11),
+ * "punc1" u8[61] / "punc2" u8[12] / "punc3" u8[8] (m17_puncture.cpp:4-10), "butterfly" u8[16][5] =
+ * the BF(v,w,x,y,z) rows (m17_conv.cpp:93-108), "crc_poly" u16 (m17_crc.cpp:4), "tx_lut" float[4]
+ * (m17_modulate.cpp:9), "sync_words" u16[4] link/stream/packet/BERT (m17_tx_routines.cpp:6-9). */
+int m17gpu_get_constant(const char *name, void *h_out, int cap_bytes);
 
 /* ---------------- output wire format (host) ----------------
  * The 54-byte M17-over-IP stream frame of the reference's reflector client

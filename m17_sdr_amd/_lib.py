@@ -64,6 +64,7 @@ SIGNATURES = {
     "m17gpu_get_lock": (_i, [_vp, _vp]),
     "m17gpu_get_taps": (_i, [_vp, _vp]),
     "m17gpu_get_golay_tables": (_i, [_vp, _vp]),
+    "m17gpu_get_constant": (_i, [C.c_char_p, _vp, _i]),
     "m17gpu_format_net_frame": (_i, [C.c_uint16, _vp, C.c_uint16, _vp, _u64, _vp]),
     "m17gpu_parse_lsf": (_i, [_vp, _vp]),
     "m17gen_channel": (_i, [C.POINTER(GenParams), _i, _vp, _vp, _vp, _i]),

@@ -20,11 +20,6 @@ def _check(rc, what):
         raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
 
-def _stream():
-    import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -38,10 +33,28 @@ class Receiver:
             raise RuntimeError("m17_sdr_amd.Receiver needs a HIP device (no CPU fallback)")
         self.C, self.max_blocks, self.device = int(n_channels), int(max_blocks), int(device)
         self.rec_cap_max = 2 * self.max_blocks + 2
-        torch.cuda.set_device(self.device)
-        torch.zeros(1, device=f"cuda:{self.device}")          # make sure torch's HIP context exists first
+        # torch's HIP context on that device must exist first; the process-wide current device is not touched
+        # (the library selects the context's device inside every call and restores the caller's)
+        torch.zeros(1, device=f"cuda:{self.device}")
         self._ctx = C.c_void_p()
         _check(lib().m17gpu_create(C.byref(self._ctx), self.C, self.max_blocks, self.device), "m17gpu_create")
+
+    def _stream(self):
+        """torch's current stream ON THIS RECEIVER'S DEVICE (not of whatever device is current)."""
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, t, dtype, shape=None, name="tensor"):
+        """Device / dtype / layout checks of a tensor handed to the C-ABI (a wrong one is an
+        out-of-bounds device access, not an exception)."""
+        import torch
+        if t is None:
+            return
+        assert isinstance(t, torch.Tensor) and t.is_cuda and t.device.index == self.device, \
+            f"{name} must live on cuda:{self.device}"
+        assert t.dtype == dtype and t.is_contiguous(), f"{name} must be contiguous {dtype}"
+        if shape is not None:
+            assert tuple(t.shape) == tuple(shape), f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}"
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
@@ -55,7 +68,7 @@ class Receiver:
             pass
 
     def reset(self):
-        _check(lib().m17gpu_reset(self._ctx, _stream()), "m17gpu_reset")
+        _check(lib().m17gpu_reset(self._ctx, self._stream()), "m17gpu_reset")
 
     # ---- hot path -------------------------------------------------------
     def alloc_outputs(self, nblk, rec_cap=None, want_syms=False):
@@ -65,7 +78,7 @@ class Receiver:
         out = {
             "recs": torch.zeros((self.C, rec_cap, 64), dtype=torch.uint8, device=dev),
             "counts": torch.zeros((self.C,), dtype=torch.int32, device=dev),
-            "syms": None, "nsyms": None, "rec_cap": rec_cap,
+            "syms": None, "nsyms": None, "rec_cap": rec_cap, "nblk": int(nblk), "C": self.C,
         }
         if want_syms:
             out["syms"] = torch.zeros((self.C, _lib.sym_stride(nblk)), dtype=torch.float32, device=dev)
@@ -74,30 +87,60 @@ class Receiver:
 
     def rx_blocks(self, iq, mode, out):
         """iq: int16 cuda tensor [C, nblk, 1920, 2]; out: dict from alloc_outputs."""
-        assert iq.is_cuda and iq.dtype.__str__() == "torch.int16" and iq.is_contiguous()
-        assert iq.shape[0] == self.C and tuple(iq.shape[2:]) == (1920, 2), iq.shape
+        import torch
+        assert iq.dim() == 4, iq.shape
         nblk = int(iq.shape[1])
+        self._chk(iq, torch.int16, (self.C, nblk, 1920, 2), "iq")
+        self._chk_out(out, nblk)
         _check(lib().m17gpu_rx_blocks(self._ctx, _ptr(iq), nblk, int(mode), _ptr(out["recs"]),
                                       int(out["rec_cap"]), _ptr(out["counts"]), _ptr(out["syms"]),
-                                      _ptr(out["nsyms"]), _stream()), "m17gpu_rx_blocks")
+                                      _ptr(out["nsyms"]), self._stream()), "m17gpu_rx_blocks")
         return out
+
+    def _chk_out(self, out, nblk):
+        """Outputs must have been allocated for this receiver and this block count: the symbol rows
+        are nblk*193+8 floats apart and nsyms is [C, nblk]."""
+        import torch
+        assert out.get("C") == self.C and out.get("nblk") == nblk, \
+            f"outputs were allocated for C={out.get('C')}, nblk={out.get('nblk')}; this call has C={self.C}, nblk={nblk}"
+        cap = int(out["rec_cap"])
+        self._chk(out["recs"], torch.uint8, (self.C, cap, 64), "out['recs']")
+        self._chk(out["counts"], torch.int32, (self.C,), "out['counts']")
+        self._chk(out["syms"], torch.float32, (self.C, _lib.sym_stride(nblk)), "out['syms']")
+        self._chk(out["nsyms"], torch.int32, (self.C, nblk), "out['nsyms']")
 
     # ---- stage entry points ----------------------------------------------
     def frontend(self, iq):
         import torch
         nblk = int(iq.shape[1])
+        self._chk(iq, torch.int16, (self.C, nblk, 1920, 2), "iq")
         disc = torch.empty((self.C, nblk, 384), dtype=torch.float32, device=iq.device)
         offs = torch.empty((self.C, nblk), dtype=torch.float32, device=iq.device)
-        _check(lib().m17gpu_frontend(self._ctx, _ptr(iq), nblk, _ptr(disc), _ptr(offs), _stream()),
+        _check(lib().m17gpu_frontend(self._ctx, _ptr(iq), nblk, _ptr(disc), _ptr(offs), self._stream()),
                "m17gpu_frontend")
         return disc, offs
 
     def sync_frame(self, disc, out):
+        import torch
         nblk = int(disc.shape[1])
+        self._chk(disc, torch.float32, (self.C, nblk, 384), "disc")
+        self._chk_out(out, nblk)
         _check(lib().m17gpu_sync_frame(self._ctx, _ptr(disc), nblk, _ptr(out["recs"]), int(out["rec_cap"]),
-                                       _ptr(out["counts"]), _ptr(out["syms"]), _ptr(out["nsyms"]), _stream()),
+                                       _ptr(out["counts"]), _ptr(out["syms"]), _ptr(out["nsyms"]), self._stream()),
                "m17gpu_sync_frame")
         return out
+
+    def sync_samples(self, disc, lock):
+        """m17_rx_sync_samples alone (m17_rx_sync.cpp:77-99) under an external framer's lock flag:
+        disc [C, nblk, 384] DC-free -> (syms [C, nblk*193+8], nsyms [C, nblk])."""
+        import torch
+        nblk = int(disc.shape[1])
+        self._chk(disc, torch.float32, (self.C, nblk, 384), "disc")
+        syms = torch.zeros((self.C, _lib.sym_stride(nblk)), dtype=torch.float32, device=disc.device)
+        nsyms = torch.zeros((self.C, nblk), dtype=torch.int32, device=disc.device)
+        _check(lib().m17gpu_sync_samples(self._ctx, _ptr(disc), nblk, int(bool(lock)), _ptr(syms), _ptr(nsyms),
+                                         self._stream()), "m17gpu_sync_samples")
+        return syms, nsyms
 
     def gen_batch(self, nblk, n_stream_frames=40, ebn0_db=200.0, base_seed=0x4D313700, first_channel=0,
                   noise_cutoff_hz=0.0):
@@ -111,7 +154,7 @@ class Receiver:
         pl = torch.zeros((self.C, max_frames, 16), dtype=torch.uint8, device=dev)
         nf = torch.zeros((self.C,), dtype=torch.int32, device=dev)
         _check(lib().m17gpu_gen_batch(self._ctx, base_seed, first_channel, nblk, n_stream_frames, ebn0_db,
-                                      noise_cutoff_hz, _ptr(iq), _ptr(lsf), _ptr(pl), max_frames, _ptr(nf), _stream()),
+                                      noise_cutoff_hz, _ptr(iq), _ptr(lsf), _ptr(pl), max_frames, _ptr(nf), self._stream()),
                "m17gpu_gen_batch")
         return {"iq": iq, "lsf": lsf, "payload": pl, "nframes": nf}
 
@@ -119,38 +162,44 @@ class Receiver:
         """wide: int16 cuda tensor [C, n_in, 2] at 384 kHz -> [C, n_in/8, 2] at 48 kHz (radio.cpp:18-40)."""
         import torch
         n_in = int(wide.shape[1])
+        self._chk(wide, torch.int16, (self.C, n_in, 2), "wide")
         out = torch.empty((self.C, n_in // 8, 2), dtype=torch.int16, device=wide.device)
-        _check(lib().m17gpu_pluto_decimate(self._ctx, _ptr(wide), n_in, _ptr(out), _stream()), "m17gpu_pluto_decimate")
+        _check(lib().m17gpu_pluto_decimate(self._ctx, _ptr(wide), n_in, _ptr(out), self._stream()), "m17gpu_pluto_decimate")
         return out
 
     def viterbi_decode(self, soft):
         import torch
         n, length = int(soft.shape[0]), int(soft.shape[1])
+        self._chk(soft, torch.float32, (n, length), "soft")
         bits = torch.empty((n, length // 2), dtype=torch.uint8, device=soft.device)
-        _check(lib().m17gpu_viterbi_decode(self._ctx, _ptr(soft), _ptr(bits), length, n, _stream()),
+        _check(lib().m17gpu_viterbi_decode(self._ctx, _ptr(soft), _ptr(bits), length, n, self._stream()),
                "m17gpu_viterbi_decode")
         return bits
 
     def demap_frame(self, sym):
         import torch
         n = int(sym.shape[0])
+        self._chk(sym, torch.float32, (n, 192), "sym")
         soft = torch.empty((n, 368), dtype=torch.float32, device=sym.device)
-        _check(lib().m17gpu_demap_frame(self._ctx, _ptr(sym), _ptr(soft), n, _stream()), "m17gpu_demap_frame")
+        _check(lib().m17gpu_demap_frame(self._ctx, _ptr(sym), _ptr(soft), n, self._stream()), "m17gpu_demap_frame")
         return soft
 
     def decode_frames(self, sym, types):
         import torch
         n = int(sym.shape[0])
+        self._chk(sym, torch.float32, (n, 192), "sym")
+        self._chk(types, torch.uint8, (n,), "types")
         recs = torch.zeros((n, 64), dtype=torch.uint8, device=sym.device)
-        _check(lib().m17gpu_decode_frames(self._ctx, _ptr(sym), _ptr(types), _ptr(recs), n, _stream()),
+        _check(lib().m17gpu_decode_frames(self._ctx, _ptr(sym), _ptr(types), _ptr(recs), n, self._stream()),
                "m17gpu_decode_frames")
         return recs
 
     def golay_decode(self, words):
         import torch
         n = int(words.shape[0])
+        self._chk(words, torch.int32, (n,), "words")
         out = torch.empty((n,), dtype=torch.int16, device=words.device)
-        _check(lib().m17gpu_golay_decode(self._ctx, _ptr(words), _ptr(out), n, _stream()), "m17gpu_golay_decode")
+        _check(lib().m17gpu_golay_decode(self._ctx, _ptr(words), _ptr(out), n, self._stream()), "m17gpu_golay_decode")
         return out
 
     def set_option(self, name, value):

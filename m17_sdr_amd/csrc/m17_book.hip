@@ -1,16 +1,12 @@
-// m17_decode_chan.hip -- k_decode_chan: frame decode + per-channel bookkeeping, one
-// 256-thread workgroup per channel (included after m17_kernels.hip).
+// m17_book.hip -- k_book_chan: per-channel, in-order bookkeeping of what m17_rx_parse / m17_aos /
+// m17_los do to file-static state, one wave per channel (included after m17_decode_quad.hip).
 //
-// Part 1 decodes the frames k_sync_frame queued for this channel, 16 at a time with 16
-// lanes per frame (decode_frame16: demap, fused gather, one-state-per-lane Viterbi,
-// Golay, packers).  Indexing frames by (channel, record) needs no global work list --
-// a returning atomicAdd per frame in the sequential framer cost 5 us each.
-// Part 2 replays the channel's records in event order for what m17_rx_parse does to
-// file-static state: LICH reassembly with its CRC, the delivery gate, the LSF gate quirk,
-// packet reassembly, the m17_dbase counters (m17_rx_parse.cpp:34-101,144-158;
-// m17_dbase.cpp:60-82).  One wave runs it with uniform control flow; the 30-byte CRC is
-// evaluated across 30 lanes: CRC-16 is linear over GF(2), so crc(msg) = crc(30 zero bytes)
-// xor XOR_i XOR_{bit k of msg[i]} E[i][k] with 240 precomputed basis words.
+// The channel's records are replayed in event order: LICH reassembly with its CRC, the delivery
+// gate, decode_link_frame's CRC quirk, packet reassembly, the m17_dbase counters
+// (m17_rx_parse.cpp:34-101,144-158; m17_dbase.cpp:60-82).  One wave runs it with uniform control
+// flow; the 30-byte CRC is evaluated across 30 lanes: CRC-16 is linear over GF(2), so
+// crc(msg) = crc(30 zero bytes) xor XOR_i XOR_{bit k of msg[i]} E[i][k] with 240 precomputed
+// basis words.
 #pragma clang fp contract(off)
 
 namespace m17dev {
@@ -89,62 +85,6 @@ __device__ __forceinline__ void lsf_shared_init(LsfShared &ls, const ChanState &
     for (int q = t; q < 256; q += nthreads) ls.crc[q] = c_tab.crc[q];
     for (int q = t; q < 16; q += nthreads) reinterpret_cast<uint32_t *>(ls.lsf)[q] = reinterpret_cast<const uint32_t *>(cs.lsf)[q];
     for (int q = t; q < 200; q += nthreads) reinterpret_cast<uint32_t *>(ls.packet)[q] = reinterpret_cast<const uint32_t *>(cs.packet)[q];
-}
-
-__device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17gpu_rec_dev *rsrc, int n, LsfShared &ls, int lane,
-                                 const uint16_t *crc_tab);
-
-__global__ __launch_bounds__(256)
-void k_decode_chan(const float *__restrict__ fsym, ChanState *__restrict__ st,
-                   m17gpu_rec_dev *__restrict__ recs, int rec_cap, const int32_t *__restrict__ counts,
-                   const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr,
-                   const uint16_t *__restrict__ crc_basis)
-{
-    __shared__ __attribute__((aligned(16))) DecShared sh_all[DEC_FRAMES_PER_WG];
-    __shared__ LsfShared ls;
-    const int t = (int)threadIdx.x, g = t >> 4, ln = t & 15;
-    const int chan = (int)blockIdx.x;
-    ChanState &cs = st[chan];
-    m17gpu_rec_dev *crecs = recs + (size_t)chan * rec_cap;
-    const int n = min(counts[chan], rec_cap);
-
-    lsf_shared_init(ls, cs, crc_basis, t, 256);
-
-    // ---- part 1: decode
-    DecShared &sh = sh_all[g];
-    for (int base = 0; base < n; base += DEC_FRAMES_PER_WG) {
-        const int item = base + g;
-        const bool active = item < n;
-        const int it = active ? item : n - 1;
-        m17gpu_rec_dev &rec = crecs[it];
-        int type = (int)rec.type;
-        const bool decodable = active && (rec.flags & M17_F_PARSED) && type >= 1 && type <= 3;
-        // the 4 groups of a wave share ballot / bpermute instructions: a group without work
-        // decodes its (valid) slot anyway and does not write back
-        if (!(type >= 1 && type <= 3)) type = 1;
-        const float *src = fsym + ((size_t)chan * rec_cap + it) * kFrameSyms;
-        if (__ballot(decodable) != 0ull) {
-            for (int q = ln; q < kFrameSyms; q += 16) sh.dep[q] = decodable ? src[q] : 0.25f;
-            if (ln < 8) reinterpret_cast<uint32_t *>(sh.bytes)[ln] = 0;
-            group_sync();
-            uint32_t fn, ge;
-            decode_frame16(sh, type, ln, genc, gerr, fn, ge);
-            if (decodable) {
-                uint32_t *r = reinterpret_cast<uint32_t *>(&rec);
-                if (ln < 8) r[5 + ln] = reinterpret_cast<const uint32_t *>(sh.bytes)[ln];
-                if (ln == 8) {
-                    r[0] = (r[0] & 0xFF00FFFFu) | ((ge & 0xFF) << 16);
-                    r[1] = (r[1] & 0x0000FFFFu) | (fn << 16);
-                }
-            }
-            group_sync();
-        }
-    }
-    __syncthreads();                     // records complete and visible to wave 0 (same CU)
-
-    // ---- part 2: in-order bookkeeping by wave 0
-    if (t >= 64) return;
-    bookkeeping_wave(cs, crecs, crecs, n, ls, t, crc_basis);
 }
 
 // What m17_rx_parse does to file-static state, replayed over the channel's records in event
@@ -236,6 +176,21 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
     group_sync();
     if (lane < 16) reinterpret_cast<uint32_t *>(cs.lsf)[lane] = reinterpret_cast<const uint32_t *>(ls.lsf)[lane];
     for (int q = lane; q < 200; q += 64) reinterpret_cast<uint32_t *>(cs.packet)[q] = reinterpret_cast<const uint32_t *>(ls.packet)[q];
+}
+
+
+// one wave per channel
+__global__ __launch_bounds__(64)
+void k_book_chan(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs, int rec_cap,
+                 const int32_t *__restrict__ counts, const uint16_t *__restrict__ crc_basis)
+{
+    __shared__ LsfShared ls;
+    const int lane = lane_id(), chan = (int)blockIdx.x;
+    ChanState &cs = st[chan];
+    m17gpu_rec_dev *crecs = recs + (size_t)chan * rec_cap;
+    lsf_shared_init(ls, cs, crc_basis, lane, 64);
+    group_sync();
+    bookkeeping_wave(cs, crecs, crecs, min(counts[chan], rec_cap), ls, lane, crc_basis);
 }
 
 } // namespace m17dev

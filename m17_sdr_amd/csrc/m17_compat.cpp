@@ -92,7 +92,10 @@ int m_17_golay_decode(uint24_t word, uint12_t &odata)      // m17_golay.cpp:103-
 int m17_rx_sync_samples(float *in, float *out, int len)    // m17_rx_sync.cpp:77-99
 {
     Chan0 &c = ch();
-    if (len != M17GPU_DISC_OUT) Chan0::die("m17_rx_sync_samples: len must be 384");
+    if (len != M17GPU_DISC_OUT) {       // the batched core works in whole 40 ms blocks; no abort: the reference has no error path
+        std::fprintf(stderr, "m17 compat shim: m17_rx_sync_samples handles len == 384 only (got %d); call ignored\n", len);
+        return 0;
+    }
     const int lock = (&m17_rx_lock != nullptr) ? (int)m17_rx_lock() : 0;
     c.up(c.d_a, in, sizeof(float) * M17GPU_DISC_OUT);
     int32_t *d_n = (int32_t *)((char *)c.d_b + 8192);
@@ -106,7 +109,10 @@ int m17_rx_sync_samples(float *in, float *out, int len)    // m17_rx_sync.cpp:77
 void m17_dsp_rx(scmplx *in, int len)                       // m17_dsp.cpp:461-476
 {
     Chan0 &c = ch();
-    if (len != M17GPU_BLOCK_SAMPLES) Chan0::die("m17_dsp_rx: len must be 1920");
+    if (len != M17GPU_BLOCK_SAMPLES) {  // every caller in the reference passes N_SAMPLES (m17_tx_rx.cpp:37,147,165)
+        std::fprintf(stderr, "m17 compat shim: m17_dsp_rx handles len == 1920 only (got %d); block ignored\n", len);
+        return;
+    }
     float tempd[M17GPU_DISC_OUT], tempc[M17GPU_BLOCK_SAMPLES / 2];
     c.up(c.d_a, in, sizeof(scmplx) * M17GPU_BLOCK_SAMPLES);
     c.ok(m17gpu_frontend(c.ctx, (const int16_t *)c.d_a, 1, (float *)c.d_b, nullptr, nullptr), "m17gpu_frontend");

@@ -1,5 +1,5 @@
 // m17_decode_quad.hip -- frame decode with FOUR lanes per frame, four trellis states per
-// lane (included after m17_decode_chan.hip).  decode_impl 2:
+// lane (included after m17_sync_*.hip):
 //
 //   k_worklist     one thread per record slot: the decodable frames of all channels are
 //                  appended to one list per frame type (wave-aggregated atomics, ~C*rec_cap/64
@@ -14,8 +14,7 @@
 //                  at a time straight from the frame symbols (demap . de-randomise .
 //                  de-interleave . de-puncture as one table gather), so a frame needs
 //                  1.5 KB of LDS and 16 frames fit a wave.
-//   k_book_chan    the in-order per-channel bookkeeping (part 2 of k_decode_chan), one wave
-//                  per channel.
+//   (k_book_chan, the in-order per-channel bookkeeping, follows in m17_book.hip.)
 //
 // Branch metrics: metric[idx] = (idx&2 ? m1 : -m1) + (idx&1 ? m2 : -m2) (m17_conv.cpp:88-91).
 // Both generators tap the newest and the oldest register bit, so the two predecessors of a
@@ -316,20 +315,6 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
 #ifdef M17_STAMPS
     if (blockIdx.x == 0 && lane == 0) { for (int i = 0; i < 7; ++i) g_stamps[i] = acc_[i]; g_stamps[8] = (unsigned long long)ntask; }
 #endif
-}
-
-// the in-order bookkeeping of k_decode_chan as its own kernel: one wave per channel
-__global__ __launch_bounds__(64)
-void k_book_chan(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs, int rec_cap,
-                 const int32_t *__restrict__ counts, const uint16_t *__restrict__ crc_basis)
-{
-    __shared__ LsfShared ls;
-    const int lane = lane_id(), chan = (int)blockIdx.x;
-    ChanState &cs = st[chan];
-    m17gpu_rec_dev *crecs = recs + (size_t)chan * rec_cap;
-    lsf_shared_init(ls, cs, crc_basis, lane, 64);
-    group_sync();
-    bookkeeping_wave(cs, crecs, crecs, min(counts[chan], rec_cap), ls, lane, crc_basis);
 }
 
 } // namespace m17dev

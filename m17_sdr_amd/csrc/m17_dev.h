@@ -12,6 +12,21 @@ constexpr int kSoftBits     = 368;
 constexpr int kPhases       = 40;     // m17_rx_sync.cpp:3
 constexpr int kTaps         = 31;     // m17_rx_sync.cpp:4
 
+#ifdef __HIPCC__
+#define M17_HD __host__ __device__
+#else
+#define M17_HD
+#endif
+// The six sync templates sframe[6][8] (m17_rx_frame.cpp:5-12) as bit masks: bit i of row k set
+// <=> template symbol i of class k is -1 (preamble, link setup, stream, packet, BERT, EOT).
+// The one definition every kernel and the host accessor m17gpu_get_constant("sframe") use.
+#define M17_SYNC_NEG_MASKS {0xAA, 0xB0, 0x4F, 0xF2, 0x0D, 0x40}
+M17_HD constexpr unsigned sync_neg_mask(int k)
+{
+    constexpr unsigned m[6] = M17_SYNC_NEG_MASKS;
+    return m[k];
+}
+
 #define M17_SYM_STRIDE(nblk) ((size_t)(nblk) * 193 + 8)
 
 #define M17_F_SYNC_OK    0x0001u

@@ -129,7 +129,7 @@ void k_gen_symbols(GenArgs A, const uint16_t *__restrict__ genc, uint8_t *__rest
     uint8_t bits[368];
     if (slot == 3) {                                                        // link setup frame, P1
         gen_encode_punctured(lsf, 30, 1, bits, 0);
-        gen_finish(0x55F7, bits, dst);
+        gen_finish(m17::kSyncLinkSetup, bits, dst);
         if (d_lsf && cyc == 0) for (int i = 0; i < 30; ++i) d_lsf[(size_t)c * 30 + i] = lsf[i];
         return;
     }
@@ -155,7 +155,7 @@ void k_gen_symbols(GenArgs A, const uint16_t *__restrict__ genc, uint8_t *__rest
         for (int b = 23; b >= 0; --b) bits[n++] = (uint8_t)((cw >> b) & 1);
     }
     gen_encode_punctured(body, 18, 2, bits, n);
-    gen_finish(0xFF5D, bits, dst);
+    gen_finish(m17::kSyncStream, bits, dst);
     // the host loop sends frame (cyc, f) only while the buffer is not yet full at its start
     const long long start = (long long)gen_delay(ch) + (long long)g * 1920;
     if (start < (long long)A.nblk * kBlockSamples) {
@@ -268,8 +268,9 @@ void k_gen_iq(GenArgs A, NoiseArgs NZ, const float *__restrict__ phase, int16_t 
     }
     if (i >= want) return;
     const float ph = phase[(size_t)c * want + i];
-    int re = (int)(int16_t)(cos((double)ph) * 0x3FFF);
-    int im = (int)(int16_t)(sin((double)ph) * 0x3FFF);
+    // single precision as the reference's overload resolution selects (m17_modulate.cpp:25-26)
+    int re = (int)(int16_t)(cosf(ph) * (float)0x3FFF);
+    int im = (int)(int16_t)(sinf(ph) * (float)0x3FFF);
     if (NZ.on) {
         double a, b;
         if (NZ.taps) {

@@ -4,6 +4,8 @@
 #include <cstdint>
 #include <cstddef>
 
+#define M17_PI 3.14159265358979323846   /* M_PI of <math.h> */
+
 namespace m17 {
 
 constexpr int kBlockSamples = 1920;   // m17defines.h:17
@@ -12,6 +14,15 @@ constexpr int kFrameSyms    = 192;    // m17defines.h:66
 constexpr int kSoftBits     = 368;
 constexpr int kPhases       = 40;     // m17_rx_sync.cpp:3  NF
 constexpr int kTaps         = 31;     // m17_rx_sync.cpp:4  FN
+
+// Transmit-side literals of the signal sources (m17_tx_routines.cpp:6-9, m17_modulate.cpp:9)
+constexpr uint16_t kSyncLinkSetup = 0x55F7, kSyncStream = 0xFF5D, kSyncPacket = 0x75FF, kSyncBert = 0xDF55;
+constexpr uint16_t kCrcPoly = 0x5935;  // m17_crc.cpp:4
+inline void tx_deviation_lut(float lut[4])     // phase step per sample of dibits 0..3
+{
+    lut[0] = (float)(M17_PI / 30.0); lut[1] = (float)(M17_PI / 10.0);
+    lut[2] = (float)(-M17_PI / 30);  lut[3] = (float)(-M17_PI / 10.0);
+}
 
 // Everything the reference builds once in main.cpp:110-118.
 struct Tables {
@@ -43,7 +54,8 @@ const Tables &tables();                // built on first use, thread-safe
 
 void build_rrc(float *f, float rolloff, int ntaps, int sps);        // m17_dsp.cpp:295-315
 void set_filter_gain(float *f, float gain, int stride, int ntaps);  // m17_dsp.cpp:420-429
-uint16_t crc16(const uint8_t *p, int n);
-void build_pluto_dec_filter(int16_t *coffs /* [31] */);          // radio.cpp:45-51                            // m17_crc.cpp:26-35
+uint16_t crc16(const uint8_t *p, int n);                           // m17_crc.cpp:26-35
+void build_pluto_dec_filter(int16_t *coffs /* [31] */);          // radio.cpp:45-51
+int puncture_keep(int type, int k);    // P1 / P2 / P3 keep flag of coded bit k (m17_puncture.cpp:4-10)
 
 } // namespace m17

@@ -7,13 +7,13 @@
 //   k_frontend_q      a3+a5+a6   int16 IQ -> limiter -> discriminator -> /5 -> DC sum      (this file)
 //                     16 (channel, block) rows per wave, 4 lanes per row; the 1920-term DC sum is a
 //                     strict sequential fp32 chain, one per row.  k_frontend: one lane per row.
-//   k_sync_frame_grp  a9+a11+a12 timing recovery + sync correlator + framer                (m17_sync_grp.hip)
+//   k_sync_frame_*    a9+a11+a12 timing recovery + sync correlator + framer                (m17_sync_*.hip)
 //   k_worklist, k_decode_quad    a14..a24 demap / gather / Viterbi / Golay / packers       (m17_decode_quad.hip)
-//   k_book_chan       a25 etc.   per-channel in-order LICH/LSF/packet bookkeeping          (m17_decode_*.hip)
+//   k_book_chan       a25 etc.   per-channel in-order LICH/LSF/packet bookkeeping          (m17_book.hip)
 //
 // Also here: the exact-arithmetic helpers with their exhaustive self tests, the sync correlator
-// (sync_check, sync_accept), the 16-lanes-per-frame decoder (decode_frame16, k_decode, and the
-// stage kernels k_viterbi / k_demap / k_golay), k_lsf and k_reset.
+// (sync_check, sync_accept), the one-state-per-lane Viterbi (viterbi16) behind the stage entry
+// points k_viterbi / k_demap / k_golay, and k_reset.
 //
 // Numeric contract: IEEE binary32, no FMA contraction, no
 // re-association, correctly rounded sqrt/divide; the double-promoted
@@ -305,7 +305,6 @@ __device__ __forceinline__ void fq_sum_chunk(const float *row, float &offset, fl
     }
 }
 
-template <int ABL>      // ABL != 0: timing-only ablations (wrong results), see scripts/exp_fe.py
 __global__ __launch_bounds__(64 * FQ_WAVES)
 void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
                   float *__restrict__ disc_raw, float *__restrict__ offs,
@@ -359,7 +358,7 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
         *reinterpret_cast<uint4 *>(&my[l1]) = s1;
         *reinterpret_cast<uint4 *>(&my[l2]) = s2;
         *reinterpret_cast<uint4 *>(&my[l3]) = s3;
-        if (!(ABL & 4)) {
+        {
             const int nx = ((chunk + 1 < FQ_NCHUNK) ? chunk + 1 : chunk) * (FQ_CHUNK / 4);
             s0 = g0[nx]; s1 = g1[nx]; s2 = g2[nx]; s3 = g3[nx];
         }
@@ -376,7 +375,7 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
         for (int e = 0; e < 16; ++e) {
             pre[e] = s16_to_float((int)(short)(w[e] & 0xFFFF));
             pim[e] = s16_to_float((int)w[e] >> 16);
-            if (!(ABL & 2)) limit(pre[e], pim[e]);
+            limit(pre[e], pim[e]);
         }
         // the two samples in front of this lane's run: neighbour lane, or the carry for sub 0
         float p0re = dpp_row_shr1(pre[15]), p0im = dpp_row_shr1(pim[15]);
@@ -401,8 +400,7 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
             *reinterpret_cast<float4 *>(&myf[cbl * FQ_STRIDE + sub * 16 + q * 4]) = make_float4(uh[0], uh[1], uh[2], uh[3]);
         }
         wave_lds_sync();
-        if (!(ABL & 1)) { if (sub == 0) fq_sum_chunk<C5>(&myf[cbl * FQ_STRIDE], offset, &myo[cbl * FQ_STRIDE]); }
-        else { offset += myf[cbl * FQ_STRIDE + sub]; myo[cbl * FQ_STRIDE + C5] = offset; }
+        if (sub == 0) fq_sum_chunk<C5>(&myf[cbl * FQ_STRIDE], offset, &myo[cbl * FQ_STRIDE]);
         wave_lds_sync();
     };
 
@@ -444,7 +442,7 @@ __device__ __forceinline__ SyncResult sync_check(const float v[8])
 {
     // bit i set = template symbol i is -1 (sframe, m17_rx_frame.cpp:5-12);
     // multiplying by +-1.0f is exact, so the running sums use add / subtract
-    constexpr unsigned neg[6] = {0xAA, 0xB0, 0x4F, 0xF2, 0x0D, 0x40};
+    constexpr unsigned neg[6] = M17_SYNC_NEG_MASKS;
     float sums[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -587,17 +585,6 @@ __device__ __forceinline__ void viterbi16(const float *dep, int len, uint16_t *d
     group_sync();
 }
 
-// pack_1_to_8(&bits[1], out, nbits) (m17_bit_utils.cpp:26-32)
-__device__ __forceinline__ void pack_bits16(const uint8_t *bits, uint8_t *out, int nbytes, int ln)
-{
-    for (int by = ln; by < nbytes; by += 16) {
-        int v = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v = (v << 1) | bits[1 + by * 8 + k];
-        out[by] = (uint8_t)v;
-    }
-}
-
 // m_17_golay_decode (m17_golay.cpp:103-116)
 __device__ __forceinline__ int golay_decode(uint32_t word, const uint16_t *enc, const uint16_t *err, int &errs)
 {
@@ -606,95 +593,6 @@ __device__ __forceinline__ int golay_decode(uint32_t word, const uint16_t *enc, 
     const uint32_t e = err[syn];
     errs = (int)((e & 0xF000) >> 12);
     return (int)(data ^ (e & 0xFFF));
-}
-
-__device__ void decode_frame16(DecShared &sh, int type, int ln,
-                               const uint16_t *genc, const uint16_t *gerr,
-                               uint32_t &fn_out, uint32_t &gerrs_out)
-{
-    demap16(sh.dep, sh.soft, ln);
-    group_sync();
-    const int len = c_tab.glen[type];
-    // fused m17_de_correlate_1 . m17_de_interleave . m17_de_punc_pN (m17_rx_parse.cpp:90-94 etc.)
-    for (int k = ln; k < len; k += 16) {
-        const int g = c_tab.gather[type][k];
-        float v = 0.0f;                                  // erasure (m17_puncture.cpp:54)
-        if (g >= 0) { v = sh.soft[g & 0x3FF]; if (g & 0x4000) v = -v; }
-        sh.dep[k] = v;
-    }
-    fn_out = 0; gerrs_out = 0;
-    if (type == 2) {
-        // LICH: four Golay words from de-interleaved positions 0..95 (m17_rx_parse.cpp:118-135)
-        int w = 0, e = 0;
-        if (ln < 4) {
-            uint32_t word = 0;
-            for (int k = 0; k < 24; ++k) {
-                const int g = c_tab.lich[ln * 24 + k];
-                float v = sh.soft[g & 0x3FF]; if (g & 0x4000) v = -v;
-                word = (word << 1) | (v >= 0.0f ? 1u : 0u);        // hard_decode_24_bits
-            }
-            w = golay_decode(word, genc, gerr, e);
-        }
-        const int w0 = shfl16i(w, 0), w1 = shfl16i(w, 1), w2 = shfl16i(w, 2), w3 = shfl16i(w, 3);
-        const int es = shfl16i(e, 0) + shfl16i(e, 1) + shfl16i(e, 2) + shfl16i(e, 3);
-        gerrs_out = (uint32_t)es;
-        if (ln == 0) {                                              // pack_12_to_8_x4x6
-            const uint32_t a = ((uint32_t)w0 << 12) | (uint32_t)w1, b = ((uint32_t)w2 << 12) | (uint32_t)w3;
-            sh.bytes[0] = (uint8_t)(a >> 16); sh.bytes[1] = (uint8_t)(a >> 8); sh.bytes[2] = (uint8_t)a;
-            sh.bytes[3] = (uint8_t)(b >> 16); sh.bytes[4] = (uint8_t)(b >> 8); sh.bytes[5] = (uint8_t)b;
-        }
-    }
-    group_sync();
-    viterbi16(sh.dep, len, sh.dec, sh.bits, ln);
-    if (type == 1) pack_bits16(sh.bits, sh.bytes, 30, ln);
-    else if (type == 2) pack_bits16(sh.bits, sh.bytes + 6, 18, ln);
-    else pack_bits16(sh.bits, sh.bytes, 26, ln);
-    group_sync();
-    if (type == 2) fn_out = ((uint32_t)sh.bytes[6] << 8) | sh.bytes[7];            // pack_8_to_16
-    if (type == 3) fn_out = ((uint32_t)(sh.bytes[25] >> 7) << 8) | ((sh.bytes[25] >> 2) & 0x1F);
-}
-
-// work-list driven decode of the frames k_sync_frame queued; or, with work ==
-// nullptr, a plain batch (frame i, type from types[i]) for the stage entry point
-__global__ __launch_bounds__(256)
-void k_decode(const float *__restrict__ fsym, const int32_t *__restrict__ work,
-              const int32_t *__restrict__ nwork, int nmax, const uint8_t *__restrict__ types,
-              m17gpu_rec_dev *__restrict__ recs,
-              const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr)
-{
-    __shared__ DecShared sh_all[DEC_FRAMES_PER_WG];
-    const int g = (int)(threadIdx.x >> 4), ln = (int)(threadIdx.x & 15);
-    const int total = work ? min(*nwork, nmax) : nmax;
-    DecShared &sh = sh_all[g];
-    // grid-stride over the work list; the 4 groups of a wave share ballot /
-    // bpermute instructions, so a group past the end repeats the last item
-    // instead of exiting and simply does not write back
-    for (int base = (int)blockIdx.x * DEC_FRAMES_PER_WG; base < total; base += (int)gridDim.x * DEC_FRAMES_PER_WG) {
-        const int item = base + g;
-        const bool active = item < total;
-        const int it = active ? item : total - 1;
-        const int slot = work ? work[it] : it;
-        m17gpu_rec_dev &rec = recs[slot];
-        int type = work ? (int)rec.type : (int)types[it];
-        const bool decodable = type >= 1 && type <= 3;
-        if (!decodable) type = 1;
-        const float *src = fsym + (size_t)slot * kFrameSyms;
-        for (int q = ln; q < kFrameSyms; q += 16) sh.dep[q] = src[q];
-        if (ln < 8) reinterpret_cast<uint32_t *>(sh.bytes)[ln] = 0;
-        group_sync();
-        uint32_t fn, ge;
-        decode_frame16(sh, type, ln, genc, gerr, fn, ge);
-        if (active && decodable) {
-            uint32_t *r = reinterpret_cast<uint32_t *>(&rec);
-            if (ln < 8) r[5 + ln] = reinterpret_cast<const uint32_t *>(sh.bytes)[ln];
-            if (ln == 8) {
-                if (!work) r[0] = (uint32_t)type;
-                r[0] = (r[0] & 0xFF00FFFFu) | ((ge & 0xFF) << 16);
-                r[1] = (r[1] & 0x0000FFFFu) | (fn << 16);
-            }
-        }
-        group_sync();
-    }
 }
 
 // stand-alone stage kernels -------------------------------------------------
@@ -739,65 +637,6 @@ __global__ void k_golay(const uint32_t *__restrict__ words, uint16_t *__restrict
     int e;
     const int d = golay_decode(words[i], genc, gerr, e);
     out[i] = (uint16_t)(d | (e << 12));
-}
-
-// ---------------------------------------------------------------------------
-// k_lsf: per-channel, in-order bookkeeping of what m17_rx_parse / m17_aos /
-// m17_los do to file-static state (m17_rx_parse.cpp:34-101,144-158; m17_dbase.cpp:60-82)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t crc16_dev(const uint8_t *p, int n)
-{
-    uint32_t crc = 0xFFFF;
-    for (int i = 0; i < n; ++i)
-        crc = ((crc << 8) ^ c_tab.crc[((crc >> 8) ^ p[i]) & 0xFF]) & 0xFFFF;
-    return crc;
-}
-
-__global__ __launch_bounds__(64)
-void k_lsf(ChanState *__restrict__ st, int C, m17gpu_rec_dev *__restrict__ recs, int rec_cap,
-           const int32_t *__restrict__ counts)
-{
-    const int chan = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (chan >= C) return;
-    ChanState &cs = st[chan];
-    const int n = min(counts[chan], rec_cap);
-    for (int i = 0; i < n; ++i) {
-        m17gpu_rec_dev &r = recs[(size_t)chan * rec_cap + i];
-        uint32_t flags = r.flags;
-        if (flags & M17_F_AOS) { cs.g_errors = 0; cs.n_frames = 0; cs.in_frame = 1; cs.frame_id_epoch++; continue; }
-        if (flags & (M17_F_EOT | M17_F_LOST)) { cs.in_frame = 0; cs.frame_id_epoch++; continue; }
-        if (!(flags & M17_F_PARSED)) continue;
-        const int type = r.type;
-        if (type == 0 || type == 5) { cs.frame_id_epoch++; }
-        else if (type == 1) {
-            if (crc16_dev(cs.packet, 30) == 0) flags |= M17_F_LSF_GATE;        // m17_rx_parse.cpp:98
-        } else if (type == 2) {
-            cs.g_errors += r.golay_errs; cs.n_frames++;
-            const int seq = r.data[5] >> 5;                                    // update_lich :71-85
-            if (seq < 6) {
-                for (int k = 0; k < 5; ++k) cs.lsf[0][seq * 5 + k] = r.data[k];
-                if (crc16_dev(cs.lsf[0], 30) == 0) {
-                    for (int k = 0; k < 30; ++k) cs.lsf[1][k] = cs.lsf[0][k];
-                    flags |= M17_F_LICH_OK;
-                }
-            }
-            if (crc16_dev(cs.lsf[1], 30) == 0) flags |= M17_F_DELIVERED;       // :148
-        } else if (type == 3) {
-            const int eof = r.data[25] >> 7, fn = (r.data[25] >> 2) & 0x1F;    // parse_packet :34-51
-            if (eof) {
-                int cnt = fn;
-                if (cs.packet_idx + cnt > 800) cnt = 800 - cs.packet_idx;
-                for (int k = 0; k < cnt; ++k) cs.packet[cs.packet_idx + k] = r.data[k];
-                cs.packet_idx += cnt;
-                if (crc16_dev(cs.packet, cs.packet_idx) == 0) flags |= M17_F_PKT_VALID;
-                cs.packet_idx = 0;
-            } else {
-                for (int k = 0; k < 25; ++k) cs.packet[fn * 25 + k] = r.data[k];
-                cs.packet_idx = fn * 25;
-            }
-        }
-        r.flags = (uint16_t)flags;
-    }
 }
 
 __global__ void k_reset(ChanState *st, int C)

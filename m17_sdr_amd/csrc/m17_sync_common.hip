@@ -1,9 +1,7 @@
-// m17_sync_wg.hip -- helpers shared by the timing/framer kernels (included by m17gpu_capi.hip
-// after m17_kernels.hip; same namespace): LDS-only barrier, s_memtime phase stamps of the
-// instrumented build, wave-parallel sync correlator, packed (matched, derivative) FIR.
-// (The workgroup-per-channel kernel this file was written for -- two waves per channel, all
-// <= 192 instants of a block at once, multi-block speculative windows -- lost to one wave per
-// channel and was removed after round 1's measurements)
+// m17_sync_common.hip -- helpers shared by the timing/framer kernels (included by m17gpu_capi.hip
+// after m17_kernels.hip; same namespace): LDS-only barrier and wave fence, s_memtime phase stamps
+// of the instrumented build, wave-parallel sync correlator, hunt pre-filter, packed (matched,
+// derivative) FIR.
 #pragma clang fp contract(off)
 
 namespace m17dev {
@@ -17,6 +15,32 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+// candidate pre-filter of the sync hunt: m17_unlocked_sync_check needs votes == 0 for
+// the winning template, i.e. no symbol of the window may have the sign OPPOSITE to
+// that template (zeros and NaNs never vote, m17_rx_frame.cpp:77-80).  A window that
+// is incompatible with all four acceptable templates (types 1..4) cannot be accepted.
+__device__ __forceinline__ bool hunt_compatible(const float v[8])
+{
+    unsigned pos = 0, neg = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        pos |= (v[i] > 0.0f) ? (1u << i) : 0u;
+        neg |= (v[i] < 0.0f) ? (1u << i) : 0u;
+    }
+    constexpr unsigned tn[4] = {sync_neg_mask(1), sync_neg_mask(2), sync_neg_mask(3), sync_neg_mask(4)};     // bit i set: template symbol i is -1
+    bool ok = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ok = ok || (((pos & tn[k]) == 0u) && ((neg & (~tn[k] & 0xFFu)) == 0u));
+    return ok;
 }
 
 #ifdef M17_STAMPS
@@ -47,7 +71,7 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
 // strict-'>' argmax walks the six lanes with readlane, the votes are a ballot.
 __device__ __forceinline__ SyncResult sync_check_wave(const float v[8])
 {
-    constexpr unsigned negs[6] = {0xAA, 0xB0, 0x4F, 0xF2, 0x0D, 0x40};
+    constexpr unsigned negs[6] = M17_SYNC_NEG_MASKS;
     const int lane = lane_id();
     unsigned neg = negs[0];
 #pragma unroll

@@ -37,7 +37,7 @@ template <int LPC> struct GrpCfg {
 template <int LPC>
 __device__ __forceinline__ SyncResult sync_check_grp(const float v[8], int gl, int gbase, int gshift)
 {
-    constexpr unsigned negs[6] = {0xAA, 0xB0, 0x4F, 0xF2, 0x0D, 0x40};
+    constexpr unsigned negs[6] = M17_SYNC_NEG_MASKS;
     unsigned neg = negs[0];
 #pragma unroll
     for (int k = 1; k < 6; ++k) neg = (gl == k) ? negs[k] : neg;
@@ -377,7 +377,9 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
             for (int r = 0; r < (kTaps - 1 + LPC - 1) / LPC; ++r)
                 keep_x[r] = (gl + LPC * r < kTaps - 1) ? my.x[kDiscOut + gl + LPC * r] : 0.0f;
             wave_fence();
-            if (!flock && gl < 8) { my.h[gl] = keep_h; cs.sync[gl] = keep_h; }
+            // (the lock-forced stage entry m17gpu_sync_samples has no framer: hunt window, block counter
+            //  and record count of the context stay as they were)
+            if (!flock && gl < 8 && ext_lock < 0) { my.h[gl] = keep_h; cs.sync[gl] = keep_h; }
 #pragma unroll
             for (int r = 0; r < (kTaps - 1 + LPC - 1) / LPC; ++r)
                 if (gl + LPC * r < kTaps - 1) my.x[gl + LPC * r] = keep_x[r];
@@ -387,7 +389,7 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
                     my.x[kTaps - 1 + gl + LPC * r] = osrc ? (pf[r] - noff) : pf[r];     // out[i] - offset
             }
         }
-        block_count++;
+        if (ext_lock < 0) block_count++;
         wave_fence();
     }
 
@@ -399,8 +401,8 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
     if (gl == 0) {
         cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum; cs.dif = dif;
         cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count;
-        cs.buff[0] = 0.0f; cs.sym_total = sym_total;
-        if (counts) counts[chan] = nrec;
+        cs.buff[0] = 0.0f;
+        if (ext_lock < 0) { cs.sym_total = sym_total; if (counts) counts[chan] = nrec; }
     }
     for (int q = gl; q < kTaps - 1; q += LPC) cs.buff[q + 1] = my.x[q];
     for (int q = gl; q < kFrameSyms; q += LPC) cs.fsym[q] = my.f[q];

@@ -3,11 +3,14 @@
 // -ffp-contract=off: the tap design must round exactly like the reference's
 // double-precision libm code.
 #include "m17_host.h"
+#include "m17_dev.h"
+#include "../../include/m17gpu.h"
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
+#include <string>
 
 namespace m17 {
 
@@ -59,7 +62,7 @@ uint16_t crc16(const uint8_t *p, int n)
     return crc;
 }
 
-static int puncture_keep(int type, int k)
+int puncture_keep(int type, int k)
 {
     switch (type) {
     case 1: return (k % 61) % 4 != 2;        // P1: 1,1,0,1 repeating, 61 long (m17_puncture.cpp:4-6)
@@ -75,7 +78,7 @@ static void build(Tables &T)
     for (int i = 0; i < 256; ++i) {
         uint16_t x = (uint16_t)(i << 8);
         for (int b = 0; b < 8; ++b)
-            x = (uint16_t)((x & 0x8000) ? ((x << 1) ^ 0x5935) : (x << 1));
+            x = (uint16_t)((x & 0x8000) ? ((x << 1) ^ kCrcPoly) : (x << 1));
         T.crc[i] = x;
     }
     // de-randomiser bits, MSB of byte 0 first
@@ -175,3 +178,42 @@ const Tables &tables()
 }
 
 } // namespace m17
+
+// Host view of the literal constants the product is built from, by name -- so that a test can hold
+// them against the values extracted from the reference's source text (tests/golden/ref_constants.json).
+// Every row is produced from the SAME definition the kernels / tables / signal sources use.
+extern "C" int m17gpu_get_constant(const char *name, void *out, int cap_bytes)
+{
+    if (!name || !out) return M17GPU_ERR_ARG;
+    const m17::Tables &T = m17::tables();
+    std::vector<uint8_t> buf;
+    auto put = [&](const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; buf.insert(buf.end(), b, b + n); };
+    const std::string nm(name);
+    if (nm == "sframe") {                       // float [6][8], +1 / -1
+        for (int k = 0; k < 6; ++k)
+            for (int i = 0; i < 8; ++i) { const float v = (m17dev::sync_neg_mask(k) >> i & 1u) ? -1.0f : 1.0f; put(&v, 4); }
+    } else if (nm == "derand_bits") {           // uint8 [368]
+        put(T.derand, sizeof T.derand);
+    } else if (nm == "golay_rows") {            // uint16 [12]: parity of the data word with only bit (11-k) set
+        for (int k = 0; k < 12; ++k) { const uint16_t v = T.golay_enc[0x800 >> k]; put(&v, 2); }
+    } else if (nm == "punc1" || nm == "punc2" || nm == "punc3") {     // uint8 [61] / [12] / [8]
+        const int ty = nm[4] - '0', per = ty == 1 ? 61 : (ty == 2 ? 12 : 8);
+        for (int k = 0; k < per; ++k) { const uint8_t v = (uint8_t)m17::puncture_keep(ty, k); put(&v, 1); }
+    } else if (nm == "butterfly") {             // uint8 [16][5]: BF(v, w, x, y, z) rows of m17_conv.cpp:93-108
+        for (int v = 0; v < 16; ++v) {
+            const uint8_t row[5] = {(uint8_t)v, (uint8_t)((2 * v) & 15), T.bm_even[v], (uint8_t)((2 * v + 1) & 15), T.bm_odd[v]};
+            put(row, 5);
+        }
+    } else if (nm == "crc_poly") {              // uint16: table entry of byte 0x01 of an MSB-first table is the polynomial
+        put(&T.crc[1], 2);
+    } else if (nm == "tx_lut") {                // float [4]
+        float lut[4]; m17::tx_deviation_lut(lut); put(lut, sizeof lut);
+    } else if (nm == "sync_words") {            // uint16 [4]: link setup, stream, packet, BERT
+        const uint16_t w[4] = {m17::kSyncLinkSetup, m17::kSyncStream, m17::kSyncPacket, m17::kSyncBert};
+        put(w, sizeof w);
+    } else
+        return M17GPU_ERR_ARG;
+    if ((int)buf.size() > cap_bytes) return M17GPU_ERR_ARG;
+    std::memcpy(out, buf.data(), buf.size());
+    return (int)buf.size();
+}

@@ -95,8 +95,7 @@ struct Modulator {
         m17::set_filter_gain(taps, 10, 1, kTxTaps * kOs);        // :74
         std::memset(hist, 0, sizeof hist);
         acc = 0;
-        lut[0] = (float)(M_PI / 30.0); lut[1] = (float)(M_PI / 10.0);   // :9
-        lut[2] = (float)(-M_PI / 30);  lut[3] = (float)(-M_PI / 10.0);
+        m17::tx_deviation_lut(lut);                              // :9
     }
     // one symbol in, 10 IQ samples out (mod_filter :49-61 + mod_fsk :22-38)
     void symbol(float dev, int16_t *out) {
@@ -107,8 +106,10 @@ struct Modulator {
             float sum = hist[0] * c[0];
             for (int j = 1; j < kTxTaps; ++j) sum += hist[j] * c[j * kOs];
             acc += sum;
-            out[2 * i]     = (int16_t)(std::cos((double)acc) * 0x3FFF);
-            out[2 * i + 1] = (int16_t)(std::sin((double)acc) * 0x3FFF);
+            // cos(m_acc) with a float argument under <math.h> in C++ resolves to the float overload,
+            // and float * int stays float (m17_modulate.cpp:25-26): single precision throughout
+            out[2 * i]     = (int16_t)(cosf(acc) * (float)0x3FFF);
+            out[2 * i + 1] = (int16_t)(sinf(acc) * (float)0x3FFF);
         }
         acc = (float)(acc / (2.0 * M_PI));       // phase wrap, :33-37
         double ip;
@@ -231,7 +232,7 @@ int m17gen_lsf_frame_dibits(const uint8_t lsf[30], uint8_t dibits[192])
     uint8_t coded[488], bits[368];
     const int n = conv_encode_bytes(lsf, 30, coded);
     if (puncture(1, coded, n, bits) != 368) return -1;
-    finish_frame(0x55F7, bits, dibits);
+    finish_frame(m17::kSyncLinkSetup, bits, dibits);
     return 192;
 }
 
@@ -255,7 +256,7 @@ int m17gen_stream_frame_dibits(const uint8_t lsf[30], int lich_count, uint16_t f
     std::memcpy(&body[2], payload, 16);
     const int nc = conv_encode_bytes(body, 18, coded);
     if (puncture(2, coded, nc, &bits[n]) != 272) return -1;
-    finish_frame(0xFF5D, bits, dibits);
+    finish_frame(m17::kSyncStream, bits, dibits);
     return 192;
 }
 
@@ -269,7 +270,7 @@ int m17gen_packet_frame_dibits(const uint8_t *payload, int len, int eof, int nf,
     tmp[25] = (uint8_t)((eof ? 0x80 : 0x00) | ((nf & 0x1F) << 2));
     conv_encode_bytes(tmp, 26, coded);
     if (puncture(3, coded, 420, bits) != 368) return -1;
-    finish_frame(0x75FF, bits, dibits);
+    finish_frame(m17::kSyncPacket, bits, dibits);
     return 192;
 }
 

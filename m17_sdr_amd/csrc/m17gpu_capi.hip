@@ -1,13 +1,12 @@
 // m17gpu_capi.hip -- the C-ABI of include/m17gpu.h on top of the gfx950 kernels.
 // No CPU fallback: every compute entry point needs a HIP device.
+#include "m17_host.h"
 #include "m17_kernels.hip"
-#include "m17_sync_wg.hip"
-#include "m17_sync_wave.hip"
+#include "m17_sync_common.hip"
 #include "m17_sync_grp.hip"
-#include "m17_sync_ring.hip"
 #include "m17_sync_duo.hip"
-#include "m17_decode_chan.hip"
 #include "m17_decode_quad.hip"
+#include "m17_book.hip"
 #include "m17_pluto.hip"
 #include "m17_gen.hip"
 #include "m17_host.h"
@@ -36,14 +35,11 @@ struct m17gpu_ctx {
     int32_t *d_work = nullptr, *d_nwork = nullptr, *d_counts = nullptr;
     uint16_t *d_genc = nullptr, *d_gerr = nullptr, *d_crc_basis = nullptr;
     uint32_t *d_dec_hist = nullptr;          // [C][32] history of the wide-band decimator
-    int lanes_per_channel = 0;               // sync_impl 4: 0 = by channel count, else 16 | 32 | 64
-    int decode_impl = 2;                     // 2 = per-type work lists + four lanes per frame + wave-per-channel bookkeeping (default),
-                                             // 1 = workgroup per channel (16 lanes per frame + bookkeeping), 0 = work list built by the framer + k_lsf
+    int lanes_per_channel = 0;               // lane-group timing kernel: 0 = by channel count, else 16 | 32 | 64
     bool profiling = false;
-    int fe_impl = 0;                         // 0 = by size, 1 = lane per channel-block, 2 = four lanes per channel-block
+    int fe_impl = 0;                         // 0 = by size (four lanes per channel-block), 1 = lane per channel-block, 2 = four lanes
     int sync_impl = 6;                       // 6 = timing wave + framer wave per channel up to 1,024 channels, lane groups beyond (default);
-                                             // 4 = lane group per channel, 5 = same with a symbol ring, 2 = wave per channel
-                                             // (also what 4 / 5 run as under decode_impl 0)
+                                             // 4 = lane group per channel at every size
     std::vector<hipEvent_t> ev_pool;         // 5 events per profiled call
     std::vector<int> ev_mode;                // mode of each profiled call
 };
@@ -60,6 +56,23 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
         if (e_ != hipSuccess)                                                          \
             return fail(M17GPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// Every entry point runs on the context's device whatever the caller's current device is, and
+// leaves the caller's device selection as it found it (the __constant__ tables and all buffers of a
+// context live on ctx->device only).
+struct DeviceScope {
+    int prev = -1, want = -1;
+    bool ok = true;
+    explicit DeviceScope(int dev) : want(dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != want && hipSetDevice(want) != hipSuccess) ok = false;
+    }
+    ~DeviceScope() { if (ok && prev != want) (void)hipSetDevice(prev); }
+};
+#define ON_CTX_DEVICE(ctx)                                                             \
+    DeviceScope dev_scope_((ctx)->device);                                             \
+    if (!dev_scope_.ok) return fail(M17GPU_ERR_HIP, "cannot select the context's device")
 
 int upload_tables(m17gpu_ctx *ctx)
 {
@@ -123,15 +136,9 @@ int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc,
     // measured on MI355X (scripts/exp_scale.py): the 4-lane kernel wins at 51,200 .. 196,608 channel-blocks,
     // so it is the default at every size; fe_impl 1 keeps the one-lane kernel selectable
     const bool quad = ctx->fe_impl != 1;
-#define LAUNCH_FQ(ABL) hipLaunchKernelGGL(k_frontend_q<ABL>, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st, \
-                           reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, disc, offs, nblk, total, update_state, b0, cbk)
-    if (ctx->fe_impl >= 100) {          // timing-only ablations of k_frontend_q (results are wrong)
-        switch (ctx->fe_impl - 100) {
-        case 1: LAUNCH_FQ(1); break; case 2: LAUNCH_FQ(2); break; case 3: LAUNCH_FQ(3); break;
-        case 4: LAUNCH_FQ(4); break; case 7: LAUNCH_FQ(7); break; default: LAUNCH_FQ(0); break;
-        }
-    } else if (quad)
-        LAUNCH_FQ(0);
+    if (quad)
+        hipLaunchKernelGGL(k_frontend_q, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st,
+                           reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, disc, offs, nblk, total, update_state, b0, cbk);
     else
         hipLaunchKernelGGL(k_frontend, dim3(cdiv(total, 64 * FE_WAVES)), dim3(64 * FE_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, disc, offs, nblk, total, update_state);
@@ -144,11 +151,10 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
                       hipStream_t st, int ext_lock = -1, int b0 = 0, int bcount = -1)
 {
     if (bcount < 0) bcount = nblk;
-    int32_t *wl = ctx->decode_impl == 0 ? ctx->d_work : nullptr;      // the work list exists only for the legacy decode path
     // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
     int lpc = ctx->lanes_per_channel;
     if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
-    if (ctx->sync_impl == 6 && ctx->decode_impl != 0 && ext_lock < 0 && lpc == 64 && ctx->C <= 1024) {
+    if (ctx->sync_impl == 6 && ext_lock < 0 && lpc == 64 && ctx->C <= 1024) {
         // timing wave + framer wave per channel (m17_sync_duo.hip): one 8-wave workgroup per CU.  Beyond 1,024
         // channels a second workgroup per CU does not fit its registers and the lane-group kernel wins (2,048 x 50:
         // 0.350 vs 0.288 ms); the lock-forced stage entry has no framer and uses the lane-group kernel too
@@ -156,20 +162,14 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
                            disc, offs, ctx->d_state, ctx->C, nblk, mode,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms, ctx->d_fsym, b0, bcount);
-    } else if ((ctx->sync_impl >= 4 && ctx->sync_impl <= 6) && ctx->decode_impl != 0) {
-#define LAUNCH_GRP(L) hipLaunchKernelGGL((ctx->sync_impl == 5 ? k_sync_frame_ring<L> : k_sync_frame_grp<L>), dim3(cdiv(ctx->C, GrpCfg<L>::CPW)), dim3(256), 0, st, \
+    } else {
+#define LAUNCH_GRP(L) hipLaunchKernelGGL(k_sync_frame_grp<L>, dim3(cdiv(ctx->C, GrpCfg<L>::CPW)), dim3(256), 0, st, \
                            disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,                                  \
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,                        \
                            d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms, ctx->d_fsym, b0, bcount)
         if (lpc == 64) LAUNCH_GRP(64); else if (lpc == 32) LAUNCH_GRP(32); else LAUNCH_GRP(16);
 #undef LAUNCH_GRP
-    } else
-        // decode_impl 0 needs the framer-built work list, which only the wave-per-channel kernel has
-        hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(ctx->C, SW_WAVES)), dim3(64 * SW_WAVES), 0, st,
-                           disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,
-                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
-                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms,
-                           ctx->d_fsym, wl, ctx->d_nwork, b0, bcount);
+    }
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -194,15 +194,13 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     if (!out || n_channels <= 0 || max_blocks <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_create: bad argument");
     if (m17gpu_device_count() <= 0)
         return fail(M17GPU_ERR_NO_DEVICE, "m17gpu_create: no HIP device visible (there is no CPU fallback)");
-    HIPCHK(hipSetDevice(device));
+    if (device < 0 || device >= m17gpu_device_count()) return fail(M17GPU_ERR_ARG, "m17gpu_create: no such device");
+    DeviceScope dev_scope_(device);                 // the caller's current device is left as it was
+    if (!dev_scope_.ok) return fail(M17GPU_ERR_HIP, "m17gpu_create: cannot select the device");
     m17gpu_ctx *ctx = new (std::nothrow) m17gpu_ctx;
     if (!ctx) return fail(M17GPU_ERR_NOMEM, "m17gpu_create: out of host memory");
     ctx->device = device; ctx->C = n_channels; ctx->max_blocks = max_blocks;
     ctx->rec_cap_max = 2 * max_blocks + 2;
-    if (const char *e = std::getenv("M17GPU_FE_IMPL")) ctx->fe_impl = std::atoi(e);
-    if (const char *e = std::getenv("M17GPU_SYNC_IMPL")) ctx->sync_impl = std::atoi(e);
-    if (const char *e = std::getenv("M17GPU_DECODE_IMPL")) ctx->decode_impl = std::atoi(e);
-    if (const char *e = std::getenv("M17GPU_LANES_PER_CHANNEL")) ctx->lanes_per_channel = std::atoi(e);
     const size_t cb = (size_t)n_channels * max_blocks;
     int rc = upload_tables(ctx);
     if (rc != M17GPU_OK) { m17gpu_destroy(ctx); return rc; }
@@ -231,7 +229,7 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
 void m17gpu_destroy(m17gpu_ctx *ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceScope dev_scope_(ctx->device);
     void *bufs[] = {ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->d_fsym, ctx->d_work,
                     ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis, ctx->d_dec_hist};
     for (void *p : bufs) (void)hipFree(p);
@@ -242,6 +240,7 @@ void m17gpu_destroy(m17gpu_ctx *ctx)
 int m17gpu_reset(m17gpu_ctx *ctx, void *stream)
 {
     if (!ctx) return fail(M17GPU_ERR_ARG, "m17gpu_reset: null context");
+    ON_CTX_DEVICE(ctx);
     const long long words = (long long)ctx->C * (long long)(sizeof(ChanState) / 4);
     hipLaunchKernelGGL(k_reset, dim3(cdiv(words, 256)), dim3(256), 0, S(stream), ctx->d_state, ctx->C);
     HIPCHK(hipGetLastError());
@@ -255,8 +254,11 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
 {
     if (!ctx || !d_iq || nblk <= 0 || nblk > ctx->max_blocks || rec_cap < 0)
         return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: bad argument (nblk must be 1..max_blocks)");
-    if ((mode & 0xFF) == 1 && (!d_recs || rec_cap <= 0 || rec_cap > ctx->rec_cap_max))
-        return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: mode 1 needs d_recs and 0 < rec_cap <= 2*max_blocks+2");
+    ON_CTX_DEVICE(ctx);
+    // mode 1: every framer event must get its record -- an event without one would also lose its frame symbols,
+    // and with them the LICH / counter / packet bookkeeping the reference does for that frame
+    if ((mode & 0xFF) == 1 && (!d_recs || rec_cap < 2 * nblk + 2 || rec_cap > ctx->rec_cap_max))
+        return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: mode 1 needs d_recs and 2*nblk+2 <= rec_cap <= 2*max_blocks+2");
     hipStream_t st = S(stream);
     int rc;
     if ((mode & 0xFF) == 1) HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t) * 4, st));
@@ -283,43 +285,21 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
     MARK(2);
     if ((mode & 0xFF) == 1) {
         int32_t *cnt = d_counts ? d_counts : ctx->d_counts;
-        if (ctx->decode_impl == 2) {
-            const long long slots = (long long)ctx->C * rec_cap;
-            hipLaunchKernelGGL(k_worklist, dim3(cdiv(slots, 1024)), dim3(1024), 0, st,
-                               reinterpret_cast<const m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->C,
-                               ctx->d_work, ctx->d_nwork, (int)slots);
-            int grid = cdiv(slots, DQ_FRAMES) + 3;
-            if (grid > 256 * 6) grid = 256 * 6;                      // 6 single-wave workgroups per CU by LDS
-            hipLaunchKernelGGL(k_decode_quad, dim3(grid), dim3(64), 0, st, ctx->d_fsym, ctx->d_work, ctx->d_nwork,
-                               (int)slots, (const uint8_t *)nullptr, 0, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
-                               ctx->d_genc, ctx->d_gerr);
-            HIPCHK(hipGetLastError());
-            MARK(3);
-            hipLaunchKernelGGL(k_book_chan, dim3(ctx->C), dim3(64), 0, st, ctx->d_state,
-                               reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->d_crc_basis);
-            HIPCHK(hipGetLastError());
-            MARK(4);
-        } else if (ctx->decode_impl == 1) {
-            hipLaunchKernelGGL(k_decode_chan, dim3(ctx->C), dim3(256), 0, st, ctx->d_fsym, ctx->d_state,
-                               reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->d_genc, ctx->d_gerr,
-                               ctx->d_crc_basis);
-            HIPCHK(hipGetLastError());
-            MARK(3);
-            MARK(4);
-        } else {
-            const long long slots = (long long)ctx->C * rec_cap;
-            int grid = cdiv(slots, DEC_FRAMES_PER_WG);
-            if (grid > 4096) grid = 4096;
-            hipLaunchKernelGGL(k_decode, dim3(grid), dim3(256), 0, st, ctx->d_fsym, ctx->d_work, ctx->d_nwork,
-                               (int)slots, (const uint8_t *)nullptr, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
-                               ctx->d_genc, ctx->d_gerr);
-            HIPCHK(hipGetLastError());
-            MARK(3);
-            hipLaunchKernelGGL(k_lsf, dim3(cdiv(ctx->C, 64)), dim3(64), 0, st, ctx->d_state, ctx->C,
-                               reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap, cnt);
-            HIPCHK(hipGetLastError());
-            MARK(4);
-        }
+        const long long slots = (long long)ctx->C * rec_cap;
+        hipLaunchKernelGGL(k_worklist, dim3(cdiv(slots, 1024)), dim3(1024), 0, st,
+                           reinterpret_cast<const m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->C,
+                           ctx->d_work, ctx->d_nwork, (int)slots);
+        int grid = cdiv(slots, DQ_FRAMES) + 3;
+        if (grid > 256 * 6) grid = 256 * 6;                      // 6 single-wave workgroups per CU by LDS
+        hipLaunchKernelGGL(k_decode_quad, dim3(grid), dim3(64), 0, st, ctx->d_fsym, ctx->d_work, ctx->d_nwork,
+                           (int)slots, (const uint8_t *)nullptr, 0, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
+                           ctx->d_genc, ctx->d_gerr);
+        HIPCHK(hipGetLastError());
+        MARK(3);
+        hipLaunchKernelGGL(k_book_chan, dim3(ctx->C), dim3(64), 0, st, ctx->d_state,
+                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->d_crc_basis);
+        HIPCHK(hipGetLastError());
+        MARK(4);
     }
 #undef MARK
     return M17GPU_OK;
@@ -346,6 +326,7 @@ int m17gpu_debug_chan_stamps(unsigned long long *out /* [4096][8] */)
 int m17gpu_selftest(m17gpu_ctx *ctx, unsigned *h_bad)
 {
     if (!ctx || !h_bad) return fail(M17GPU_ERR_ARG, "m17gpu_selftest: bad argument");
+    ON_CTX_DEVICE(ctx);
     unsigned *d_bad = nullptr;
     HIPCHK(hipMalloc(&d_bad, 4 * sizeof(unsigned)));
     HIPCHK(hipMemset(d_bad, 0, 4 * sizeof(unsigned)));
@@ -362,16 +343,19 @@ int m17gpu_selftest(m17gpu_ctx *ctx, unsigned *h_bad)
     return M17GPU_OK;
 }
 
-// Implementation selectors, for A/B measurements and so that every kernel variant stays
-// under the parity tests: "sync_impl" 2|4|5, "lanes_per_channel" 0|16|32|64,
-// "fe_impl" 0|1|2, "decode_impl" 0|1|2.
+// Implementation selectors, for A/B measurements and so that every kernel variant stays under the
+// parity tests.  Every accepted value selects a kernel that is held to bit-exact parity; anything
+// else is rejected.
 int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
-    if (!std::strcmp(name, "sync_impl")) ctx->sync_impl = value;
-    else if (!std::strcmp(name, "fe_impl")) ctx->fe_impl = value;
-    else if (!std::strcmp(name, "decode_impl")) ctx->decode_impl = value;
-    else if (!std::strcmp(name, "lanes_per_channel")) ctx->lanes_per_channel = value;
+    auto bad = [&]() { return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: value out of range for ") + name); };
+    if (!std::strcmp(name, "sync_impl")) { if (value != 4 && value != 6) return bad(); ctx->sync_impl = value; }
+    else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 2) return bad(); ctx->fe_impl = value; }
+    else if (!std::strcmp(name, "lanes_per_channel")) {
+        if (value != 0 && value != 16 && value != 32 && value != 64) return bad();
+        ctx->lanes_per_channel = value;
+    }
     else return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: unknown option ") + name);
     return M17GPU_OK;
 }
@@ -386,6 +370,7 @@ int m17gpu_set_profiling(m17gpu_ctx *ctx, int on)
 int m17gpu_get_kernel_ms(m17gpu_ctx *ctx, float h_ms[4], int *h_calls)
 {
     if (!ctx || !h_ms) return fail(M17GPU_ERR_ARG, "m17gpu_get_kernel_ms: bad argument");
+    ON_CTX_DEVICE(ctx);
     double acc[4] = {0, 0, 0, 0};
     int n[4] = {0, 0, 0, 0};
     const size_t calls = ctx->ev_mode.size();
@@ -411,6 +396,7 @@ int m17gpu_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *d_dis
 {
     if (!ctx || !d_iq || !d_disc || nblk <= 0 || nblk > ctx->max_blocks)
         return fail(M17GPU_ERR_ARG, "m17gpu_frontend: bad argument");
+    ON_CTX_DEVICE(ctx);
     hipStream_t st = S(stream);
     float *offs = d_offset ? d_offset : ctx->d_offs;
     int rc = launch_frontend(ctx, d_iq, nblk, d_disc, offs, 1, st);
@@ -425,6 +411,7 @@ int m17gpu_sync_frame(m17gpu_ctx *ctx, const float *d_disc, int nblk, m17gpu_rec
                       int32_t *d_counts, float *d_syms, int32_t *d_nsyms, void *stream)
 {
     if (!ctx || !d_disc || nblk <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_sync_frame: bad argument");
+    ON_CTX_DEVICE(ctx);
     return launch_sync_frame(ctx, d_disc, nullptr, nblk, 0, d_recs, rec_cap, d_counts, d_syms, d_nsyms, S(stream));
 }
 
@@ -432,6 +419,7 @@ int m17gpu_pluto_decimate(m17gpu_ctx *ctx, const int16_t *d_in, int n_in, int16_
 {
     if (!ctx || !d_in || !d_out || n_in < 32 || (n_in & 7))
         return fail(M17GPU_ERR_ARG, "m17gpu_pluto_decimate: n_in must be a multiple of 8 and >= 32");
+    ON_CTX_DEVICE(ctx);
     hipStream_t st = S(stream);
     const int M = n_in / 8, wpc = (M + 60) / 61;
     hipLaunchKernelGGL(k_pluto_decimate, dim3(cdiv((long long)ctx->C * wpc, 4)), dim3(256), 0, st,
@@ -453,6 +441,7 @@ int m17gpu_gen_batch(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int
 {
     if (!ctx || !d_iq || nblk <= 0 || n_stream_frames < 0 || (d_payload && max_payload_frames <= 0))
         return fail(M17GPU_ERR_ARG, "m17gpu_gen_batch: bad argument");
+    ON_CTX_DEVICE(ctx);
     hipStream_t st = S(stream);
     const long long want = (long long)nblk * kBlockSamples;
     // modulator taps and deviations exactly as the host generator builds them (m17_modulate.cpp:9,73-74)
@@ -461,8 +450,7 @@ int m17gpu_gen_batch(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int
     m17::set_filter_gain(taps, 10, 1, 310);
     GenArgs A;
     A.base_seed = base_seed; A.nblk = nblk; A.n_stream_frames = n_stream_frames; A.nslots = nblk + 1;
-    A.lut[0] = (float)(M_PI / 30.0); A.lut[1] = (float)(M_PI / 10.0);
-    A.lut[2] = (float)(-M_PI / 30);  A.lut[3] = (float)(-M_PI / 10.0);
+    m17::tx_deviation_lut(A.lut);
     NoiseArgs NZ;
     std::memset(&NZ, 0, sizeof NZ);
     if (ebn0_db < 100.0f) {
@@ -487,6 +475,10 @@ int m17gpu_gen_batch(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int
     if (group > ctx->C) group = ctx->C;
     float *d_taps = nullptr, *d_sum = nullptr;
     uint8_t *d_sym = nullptr;
+    struct Workspace {                              // freed on every return path
+        float *&a, *&b; uint8_t *&c;
+        ~Workspace() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); }
+    } ws_{d_taps, d_sum, d_sym};
     HIPCHK(hipMalloc(&d_taps, sizeof taps));
     HIPCHK(hipMemcpyAsync(d_taps, taps, sizeof taps, hipMemcpyHostToDevice, st));
     HIPCHK(hipMalloc(&d_sum, sizeof(float) * (size_t)group * want));
@@ -506,8 +498,7 @@ int m17gpu_gen_batch(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int
                            d_iq + (size_t)c0 * want * 2);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipStreamSynchronize(st));                       // the workspace is freed here
-    (void)hipFree(d_taps); (void)hipFree(d_sum); (void)hipFree(d_sym);
+    HIPCHK(hipStreamSynchronize(st));                       // the workspace is freed on return
     return M17GPU_OK;
 }
 
@@ -515,6 +506,7 @@ int m17gpu_sync_samples(m17gpu_ctx *ctx, const float *d_disc, int nblk, int lock
                         int32_t *d_nsyms, void *stream)
 {
     if (!ctx || !d_disc || !d_syms || nblk <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_sync_samples: bad argument");
+    ON_CTX_DEVICE(ctx);
     return launch_sync_frame(ctx, d_disc, nullptr, nblk, 0, nullptr, 0, nullptr, d_syms, d_nsyms, S(stream),
                              lock ? 1 : 0);
 }
@@ -523,6 +515,7 @@ int m17gpu_viterbi_decode(m17gpu_ctx *ctx, const float *d_soft, uint8_t *d_bits,
 {
     if (!ctx || !d_soft || !d_bits || len <= 0 || len > 488 || (len & 1) || n <= 0)
         return fail(M17GPU_ERR_ARG, "m17gpu_viterbi_decode: len must be even and <= 488");
+    ON_CTX_DEVICE(ctx);
     hipLaunchKernelGGL(k_viterbi, dim3(cdiv(n, DEC_FRAMES_PER_WG)), dim3(256), 0, S(stream), d_soft, d_bits, len, n);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
@@ -531,6 +524,7 @@ int m17gpu_viterbi_decode(m17gpu_ctx *ctx, const float *d_soft, uint8_t *d_bits,
 int m17gpu_demap_frame(m17gpu_ctx *ctx, const float *d_sym, float *d_soft, int n, void *stream)
 {
     if (!ctx || !d_sym || !d_soft || n <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_demap_frame: bad argument");
+    ON_CTX_DEVICE(ctx);
     hipLaunchKernelGGL(k_demap, dim3(cdiv(n, DEC_FRAMES_PER_WG)), dim3(256), 0, S(stream), d_sym, d_soft, n);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
@@ -539,21 +533,14 @@ int m17gpu_demap_frame(m17gpu_ctx *ctx, const float *d_sym, float *d_soft, int n
 int m17gpu_decode_frames(m17gpu_ctx *ctx, const float *d_sym, const uint8_t *d_type, m17gpu_rec *d_recs, int n, void *stream)
 {
     if (!ctx || !d_sym || !d_type || !d_recs || n <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_decode_frames: bad argument");
+    ON_CTX_DEVICE(ctx);
     hipStream_t st = S(stream);
     HIPCHK(hipMemsetAsync(d_recs, 0, sizeof(m17gpu_rec) * (size_t)n, st));
-    if (ctx->decode_impl == 2) {
-        int grid = cdiv(n, DQ_FRAMES);
-        if (grid > 256 * 6) grid = 256 * 6;
-        hipLaunchKernelGGL(k_decode_quad, dim3(grid), dim3(64), 0, st, d_sym, (const int32_t *)nullptr,
-                           (const int32_t *)nullptr, 0, d_type, n, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
-                           ctx->d_genc, ctx->d_gerr);
-    } else {
-        int grid = cdiv(n, DEC_FRAMES_PER_WG);
-        if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(k_decode, dim3(grid), dim3(256), 0, st, d_sym, (const int32_t *)nullptr,
-                           (const int32_t *)nullptr, n, d_type, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
-                           ctx->d_genc, ctx->d_gerr);
-    }
+    int grid = cdiv(n, DQ_FRAMES);
+    if (grid > 256 * 6) grid = 256 * 6;
+    hipLaunchKernelGGL(k_decode_quad, dim3(grid), dim3(64), 0, st, d_sym, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr, 0, d_type, n, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
+                       ctx->d_genc, ctx->d_gerr);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -561,6 +548,7 @@ int m17gpu_decode_frames(m17gpu_ctx *ctx, const float *d_sym, const uint8_t *d_t
 int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_out, int n, void *stream)
 {
     if (!ctx || !d_words || !d_out || n <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_golay_decode: bad argument");
+    ON_CTX_DEVICE(ctx);
     hipLaunchKernelGGL(k_golay, dim3(cdiv(n, 256)), dim3(256), 0, S(stream), d_words, d_out, n, ctx->d_genc, ctx->d_gerr);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
@@ -577,6 +565,7 @@ static int fetch_state(m17gpu_ctx *ctx, std::vector<ChanState> &h)
 int m17gpu_get_lsf(m17gpu_ctx *ctx, uint8_t *h_lsf)
 {
     if (!ctx || !h_lsf) return fail(M17GPU_ERR_ARG, "m17gpu_get_lsf: bad argument");
+    ON_CTX_DEVICE(ctx);
     std::vector<ChanState> h; int rc = fetch_state(ctx, h); if (rc) return rc;
     for (int c = 0; c < ctx->C; ++c)
         for (int k = 0; k < 2; ++k) std::memcpy(h_lsf + ((size_t)c * 2 + k) * 30, h[c].lsf[k], 30);
@@ -586,6 +575,7 @@ int m17gpu_get_lsf(m17gpu_ctx *ctx, uint8_t *h_lsf)
 int m17gpu_get_counters(m17gpu_ctx *ctx, uint32_t *h_cnt)
 {
     if (!ctx || !h_cnt) return fail(M17GPU_ERR_ARG, "m17gpu_get_counters: bad argument");
+    ON_CTX_DEVICE(ctx);
     std::vector<ChanState> h; int rc = fetch_state(ctx, h); if (rc) return rc;
     for (int c = 0; c < ctx->C; ++c) {
         h_cnt[4 * c + 0] = h[c].g_errors; h_cnt[4 * c + 1] = h[c].n_frames;
@@ -597,6 +587,7 @@ int m17gpu_get_counters(m17gpu_ctx *ctx, uint32_t *h_cnt)
 int m17gpu_get_lock(m17gpu_ctx *ctx, uint8_t *h_lock)
 {
     if (!ctx || !h_lock) return fail(M17GPU_ERR_ARG, "m17gpu_get_lock: bad argument");
+    ON_CTX_DEVICE(ctx);
     std::vector<ChanState> h; int rc = fetch_state(ctx, h); if (rc) return rc;
     for (int c = 0; c < ctx->C; ++c) h_lock[c] = (uint8_t)(h[c].flock != 0);
     return M17GPU_OK;

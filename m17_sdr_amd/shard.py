@@ -1,11 +1,18 @@
 """Channel sharding across the GPUs of one node.
 
-The path shards by channel with no data-path collective: rank r owns the
-contiguous channel range channel_range(r, world, C) and keeps that range's state
-on its own GPU for the life of the stream.  The only exchange is the optional
-gather of the 64-byte decoded-frame records to one rank (RCCL when the tensors
-are on GPUs, gloo in the CPU tests) -- about 1 MB per 16,384 channels per step
-against 125.8 MB of IQ, so it is kept off the timed path by default."""
+The path shards by channel with no data-path collective: rank r owns the contiguous channel range
+channel_range(r, world, C) and keeps that range's state on its own GPU for the life of the stream.
+The only exchanges are at the edges of a step, both point-to-point from / to one ingest rank:
+
+    scatter_iq      the IQ of all channels fans out from the ingest rank, one send per peer (xGMI is a
+                    full mesh: 7 links x ~153 GB/s, so 7 direct sends run on 7 links; a ring would be
+                    per-link bound for no benefit)
+    gather_records  the 64-byte decoded-frame records come back (about 1 MB per 16,384 channels per
+                    step against 125.8 MB of IQ per block)
+
+With the "nccl" backend (= RCCL on ROCm) device tensors move GPU to GPU.  Backends that cannot move
+device tensors (gloo: CPU tests, and the 1-GPU rehearsal of bench.py) stage through host memory; the
+call sites are the same."""
 import torch
 import torch.distributed as dist
 
@@ -17,20 +24,26 @@ def channel_range(rank, world, n_channels):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _moves_device_tensors(group=None):
+    return dist.get_backend(group) == "nccl"
+
+
 def gather_records(recs, counts, dst=0, group=None):
     """Gather per-rank records [Cr, cap, 64] (uint8) and counts [Cr] (int32) to `dst`.
 
     Ranks may own different numbers of channels; shards are padded to the largest.
-    Returns (recs [C, cap, 64], counts [C]) on dst, (None, None) elsewhere."""
+    Returns (recs [C, cap, 64], counts [C]) on dst (on the device the inputs live on), (None, None) elsewhere."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    n = torch.tensor([recs.shape[0]], dtype=torch.int64, device=recs.device)
+    home = recs.device
+    wire = home if (_moves_device_tensors(group) or home.type == "cpu") else torch.device("cpu")
+    n = torch.tensor([recs.shape[0]], dtype=torch.int64, device=wire)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
     cmax = max(sizes)
-    pad_r = torch.zeros((cmax,) + tuple(recs.shape[1:]), dtype=recs.dtype, device=recs.device)
-    pad_c = torch.zeros((cmax,), dtype=counts.dtype, device=counts.device)
+    pad_r = torch.zeros((cmax,) + tuple(recs.shape[1:]), dtype=recs.dtype, device=wire)
+    pad_c = torch.zeros((cmax,), dtype=counts.dtype, device=wire)
     pad_r[:recs.shape[0]] = recs
     pad_c[:counts.shape[0]] = counts
     out_r = [torch.empty_like(pad_r) for _ in range(world)] if rank == dst else None
@@ -39,31 +52,38 @@ def gather_records(recs, counts, dst=0, group=None):
     dist.gather(pad_c, out_c, dst=dst, group=group)
     if rank != dst:
         return None, None
-    return (torch.cat([out_r[r][:sizes[r]] for r in range(world)]),
-            torch.cat([out_c[r][:sizes[r]] for r in range(world)]))
+    return (torch.cat([out_r[r][:sizes[r]] for r in range(world)]).to(home),
+            torch.cat([out_c[r][:sizes[r]] for r in range(world)]).to(home))
 
 
-def scatter_iq(iq_full, n_channels, src=0, group=None, device=None):
-    """Fan the [C, nblk, 1920, 2] int16 IQ of `src` out to the owning ranks
-    (point-to-point sends, one per peer: xGMI is a full mesh, no ring needed)."""
+def scatter_iq(iq_full, n_channels, nblk, src=0, group=None, device=None):
+    """Fan the [C, nblk, 1920, 2] int16 IQ held by `src` out to the owning ranks: one point-to-point
+    send per peer.  Non-source ranks pass iq_full=None.  Returns this rank's shard
+    [hi-lo, nblk, 1920, 2] on `device` (default: the source tensor's device / the current device)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = channel_range(rank, world, n_channels)
+    direct = _moves_device_tensors(group)
     if rank == src:
-        reqs = []
+        assert iq_full is not None and tuple(iq_full.shape) == (n_channels, nblk, 1920, 2) and iq_full.dtype == torch.int16
+        home = device if device is not None else iq_full.device
+        reqs, keep = [], []
         for r in range(world):
             a, b = channel_range(r, world, n_channels)
             if r != src and b > a:
-                reqs.append(dist.isend(iq_full[a:b].contiguous(), dst=r, group=group))
-        mine = iq_full[lo:hi].contiguous()
+                part = iq_full[a:b]                                  # contiguous: a range of whole channels
+                if not direct and part.device.type != "cpu":
+                    part = part.cpu()
+                keep.append(part)
+                reqs.append(dist.isend(part, dst=r, group=group))
+        mine = iq_full[lo:hi].to(home)
         for q in reqs:
             q.wait()
         return mine
-    shape = (hi - lo,) + tuple(iq_full.shape[1:]) if iq_full is not None else None
-    raise_if = shape is None
-    if raise_if:
-        raise ValueError("non-source ranks pass a template tensor of the full shape (any device)")
-    mine = torch.empty(shape, dtype=torch.int16, device=device or iq_full.device)
+    assert iq_full is None, "only the source rank passes the full IQ tensor"
+    home = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    wire = home if direct else torch.device("cpu")
+    mine = torch.empty((hi - lo, nblk, 1920, 2), dtype=torch.int16, device=wire)
     if hi > lo:
         dist.recv(mine, src=src, group=group)
-    return mine
+    return mine.to(home)

@@ -177,6 +177,33 @@ const uint16_t *m17o_tab_golay_enc(void) { return t_genc; }
 const uint16_t *m17o_tab_golay_err(void) { return t_gerr; }
 const uint8_t *m17o_tab_derand(void) { return t_derand; }
 const uint16_t *m17o_tab_crc(void) { return t_crc; }
+
+/* The literal constants this restatement is built from, by name, for the test that holds them
+ * against the values extracted from the reference's source text (tests/golden/ref_constants.json).
+ * Returns the number of bytes written, or -1. */
+int m17o_get_constant(const char *name, void *out, int cap)
+{
+    uint8_t buf[256];
+    int n = 0;
+    m17o_init();
+    if (!strcmp(name, "sframe")) { memcpy(buf, t_sframe, sizeof t_sframe); n = sizeof t_sframe; }
+    else if (!strcmp(name, "derand_bytes")) { memcpy(buf, t_ctab, 46); n = 46; }
+    else if (!strcmp(name, "golay_rows")) { memcpy(buf, t_gtab, sizeof t_gtab); n = sizeof t_gtab; }
+    else if (!strcmp(name, "punc1")) { memcpy(buf, t_p1, 61); n = 61; }
+    else if (!strcmp(name, "punc2")) { memcpy(buf, t_p2, 12); n = 12; }
+    else if (!strcmp(name, "punc3")) { memcpy(buf, t_p3, 8); n = 8; }
+    else if (!strcmp(name, "butterfly")) {          /* BF(v,w,x,y,z) rows */
+        for (int v = 0; v < 16; v++) {
+            buf[n++] = (uint8_t)v;
+            for (int k = 0; k < 4; k++) buf[n++] = t_bf[v][k];
+        }
+    }
+    else if (!strcmp(name, "crc_poly")) { memcpy(buf, &t_crc[1], 2); n = 2; }  /* MSB-first table: entry 1 is the polynomial */
+    else return -1;
+    if (n > cap) return -1;
+    memcpy(out, buf, (size_t)n);
+    return n;
+}
 int m17o_sizeof_chan(void) { return (int)sizeof(m17o_chan); }
 
 /* zero-initialised statics + m17_rx_sync.cpp:123-126 */

@@ -91,6 +91,9 @@ const uint16_t *m17o_tab_golay_enc(void);              /* [4096] */
 const uint16_t *m17o_tab_golay_err(void);              /* [4096] */
 const uint8_t *m17o_tab_derand(void);                  /* [368] */
 const uint16_t *m17o_tab_crc(void);                    /* [256] */
+/* literal constants by name: "sframe" f32[6][8], "derand_bytes" u8[46], "golay_rows" u16[12],
+ * "punc1|2|3" u8[61|12|8], "butterfly" u8[16][5] = BF(v,w,x,y,z), "crc_poly" u16; bytes written or -1 */
+int m17o_get_constant(const char *name, void *out, int cap);
 
 /* ---- primitives ---- */
 void     m17o_build_rrc_filter(float *f, float rolloff, int ntaps, int sps);

@@ -3,9 +3,12 @@
 the CPU oracle on the same IQ.  Same input => the two curves must coincide exactly;
 the script also reports payload BER against the transmitted truth.
 
-    python scripts/ber_sweep.py --channels 16384 --blocks 30 --out profiles/ber_r01.json
-Eb/N0 = Es/N0 - 3 dB, Es = A^2 x 10 samples, N0 = noise PSD (complex variance per 48 kHz
-sample before the channel filter).  The reference has no software channel filter ahead of
+    python scripts/ber_sweep.py --channels 16384 --blocks 30 --out profiles/r02_ber_sweep_16384ch.json
+Axis: the generator's `ebn0_db` is energy per CHANNEL bit over N0: Es/N0 - 3 dB (two channel bits per
+4-FSK symbol), Es = A^2 x 10 samples, N0 = noise PSD (complex variance per 48 kHz sample before the
+channel filter).  Per INFORMATION bit of the stream payload the code rate comes on top (SURVEY 8d,
+Es = 2 Eb R): R = 144/272 for the P2-punctured K=5 code, i.e. Eb_info/N0 = axis + 2.76 dB; both are
+written to the JSON.  EVERY channel of every point goes through the CPU oracle as well.  The reference has no software channel filter ahead of
 its limiter, so the noise is band-limited here (default 6.25 kHz one-sided = a 12.5 kHz
 channel) like a radio front end would; with white 48 kHz noise nothing decodes below
 ~17 dB (FM threshold)."""
@@ -35,11 +38,13 @@ def main():
     ap.add_argument("--blocks", type=int, default=30)
     ap.add_argument("--chunk", type=int, default=2048, help="channels generated / processed per pass")
     ap.add_argument("--ebn0", type=float, nargs="*", default=[float(x) for x in range(0, 11)])
-    ap.add_argument("--oracle-channels", type=int, default=512, help="channels per point also run through the CPU oracle")
+    ap.add_argument("--oracle-channels", type=int, default=-1, help="channels per point also run through the CPU oracle (-1 = all)")
     ap.add_argument("--noise-cutoff", type=float, default=6250.0, help="one-sided channel-filter cutoff applied to the noise, Hz (0 = white over 48 kHz)")
     ap.add_argument("--gen", choices=["gpu", "host"], default="gpu", help="signal source (SURVEY 8f-1 device generator, or the host one)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
+    if a.oracle_channels < 0:
+        a.oracle_channels = a.channels
     if a.gen == "gpu":
         a.chunk = a.channels                      # the whole config in one launch, as BASELINE config #4 words it
     import torch
@@ -77,7 +82,7 @@ def main():
                 tot["identical"] = tot["identical"] and bool(same)
                 tot["checked"] += k
             rx.close()
-        row = {"ebn0_db": eb, "payload_bits": tot["bits"], "bit_errors": tot["bit_err"],
+        row = {"ebn0_db": eb, "ebn0_info_bit_db": round(eb + 10 * np.log10(272 / 144), 2), "payload_bits": tot["bits"], "bit_errors": tot["bit_err"],
                "ber": (tot["bit_err"] / tot["bits"]) if tot["bits"] else None,
                "frames_decoded": tot["frames"], "frames_sent": tot["sent"],
                "fer": 1.0 - tot["frames"] / max(1, tot["sent"]),
@@ -86,7 +91,12 @@ def main():
         rows.append(row)
         print(json.dumps(row), flush=True)
     if a.out:
-        json.dump({"channels": a.channels, "blocks": a.blocks, "noise_cutoff_hz": a.noise_cutoff, "signal_source": a.gen, "points": rows}, open(a.out, "w"), indent=1)
+        json.dump({"channels": a.channels, "blocks": a.blocks, "noise_cutoff_hz": a.noise_cutoff, "signal_source": a.gen,
+                   "axis": "ebn0_db = energy per CHANNEL bit / N0 = Es/N0 - 3.01 dB (2 channel bits per 4-FSK symbol; Es = A^2 x 10 "
+                           "samples; N0 = complex noise variance per 48 kHz sample before the 12.5 kHz channel filter); "
+                           "ebn0_info_bit_db adds the code-rate term of SURVEY 8(d), R = 144/272 (P2-punctured K=5): +2.76 dB",
+                   "oracle": "every channel of every point also decoded by the CPU oracle; gpu_equals_oracle = all records identical",
+                   "points": rows}, open(a.out, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,90 @@
+"""GPU tests of the multi-rank launch path.  This file sorts first on purpose: the 2-rank rehearsal
+starts child processes, and it does so before the test process itself has touched the GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_starts_its_own_ranks_gloo_rehearsal():
+    """`python bench.py --gpus 2` must start two ranks itself (no torchrun) and report n_gpus == 2, with the
+    fan-out legs (shard.scatter_iq -> compute -> shard.gather_records) timed apart.  On a 1-GPU box the two
+    ranks share the card and the collectives run over gloo (M17_BENCH_BACKEND=gloo); on a multi-GPU node
+    the same code path runs one rank per GPU over RCCL."""
+    env = dict(os.environ, M17_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--channels", "96", "--blocks", "6", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak"
+    assert line["config"]["channels_total"] == 192 and line["value"] > 0
+    assert line["fanout"]["fanout_ms"] > 0 and line["fanout"]["gather_ms"] > 0
+    assert line["roofline"]["calls_timed"] == 4 and line["roofline"]["frac"] > 0
+
+
+def test_scatter_and_gather_with_device_tensors_over_rccl():
+    """shard.scatter_iq / shard.gather_records with CUDA tensors on the nccl (= RCCL) backend.  One device is
+    all a test box has, so the group has one rank: the calls, tensor placement and the record layout are the
+    ones the N-rank bench uses; the result must equal the receiver's own output and the oracle's."""
+    import torch
+    import torch.distributed as dist
+    assert torch.cuda.is_available()
+    import m17_sdr_amd as m
+    from m17_sdr_amd.shard import gather_records, scatter_iq
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        C, nblk = 50, 8
+        sig = m.generate_batch(C, nblk, n_stream_frames=4)
+        full = torch.from_numpy(sig["iq"]).cuda()
+        mine = scatter_iq(full, C, nblk, src=0)
+        assert mine.is_cuda and mine.shape == full.shape
+        rx = m.Receiver(C, nblk)
+        out = rx.rx_blocks(mine.contiguous(), 1, rx.alloc_outputs(nblk))
+        gr, gc = gather_records(out["recs"], out["counts"], dst=0)
+        torch.cuda.synchronize()
+        assert gr.is_cuda and gc.is_cuda
+        ref = oracle.Channels(C).rx_blocks(sig["iq"], mode=1, want_syms=False)
+        np.testing.assert_array_equal(gc.cpu().numpy(), ref["counts"])
+        recs = gr.cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
+        for c in range(C):
+            assert recs[c, :ref["counts"][c]].tobytes() == ref["recs"][c, :ref["counts"][c]].tobytes()
+        rx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_receivers_do_not_depend_on_the_current_device():
+    """Every C-ABI entry selects its context's device itself (and restores the caller's); the Python handle takes
+    the stream of ITS device.  With one GPU the check is that a foreign 'current device' request is harmless and
+    that create() rejects a device that does not exist."""
+    import torch
+    import m17_sdr_amd as m
+    n = torch.cuda.device_count()
+    with pytest.raises(RuntimeError):
+        m.Receiver(2, 2, device=n)                         # no such device
+    rx = [m.Receiver(8, 4, device=d) for d in range(min(n, 2))] * (2 if n == 1 else 1)
+    sig = m.generate_batch(8, 4, n_stream_frames=2)
+    ref = oracle.Channels(8).rx_blocks(sig["iq"], mode=1, want_syms=False)
+    for k, r in enumerate(rx[:2]):
+        torch.cuda.set_device((k + 1) % n)                 # "current" device differs from the receiver's when n > 1
+        iq = torch.from_numpy(sig["iq"]).to(f"cuda:{r.device}")
+        r.reset()
+        out = r.rx_blocks(iq, 1, r.alloc_outputs(4))
+        torch.cuda.synchronize(r.device)
+        np.testing.assert_array_equal(out["counts"].cpu().numpy(), ref["counts"])
+        assert torch.cuda.current_device() == (k + 1) % n
+    for r in set(rx):
+        r.close()
+    torch.cuda.set_device(0)

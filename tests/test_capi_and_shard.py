@@ -75,10 +75,10 @@ from tests import oracle
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 C, nblk = 7, 10
-full = torch.zeros((C, nblk, 1920, 2), dtype=torch.int16)
+full = None
 if rank == 0:
     full = torch.from_numpy(m.generate_batch(C, nblk, n_stream_frames=4)["iq"])
-mine = scatter_iq(full, C, src=0)
+mine = scatter_iq(full, C, nblk, src=0, device=torch.device("cpu"))
 lo, hi = channel_range(rank, world, C)
 assert mine.shape[0] == hi - lo
 # the oracle stands in for the per-GPU receive chain in this CPU test

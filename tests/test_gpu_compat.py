@@ -13,12 +13,54 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_shim_functions_match_oracle():
+@pytest.fixture(scope="module")
+def harness():
+    """The caller-side harness (tests/compat/rx_frame_harness.cpp) defines m17_rx_symbols / m17_rx_lock,
+    which libm17compat.so references weakly -- as the reference's m17_rx_frame.cpp would.  It must be in
+    the global symbol scope BEFORE the shim is loaded so the shim binds to it, hence RTLD_GLOBAL and a
+    module fixture every test of this file depends on."""
     import torch
     assert torch.cuda.is_available()
     import m17_sdr_amd as m
     m.lib()
     torch.zeros(1, device="cuda")
+    H = C.CDLL(os.path.join(ROOT, "tests", "compat", "libm17compat_harness.so"), mode=C.RTLD_GLOBAL)
+    H.harness_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    return H
+
+
+def test_block_entry_m17_dsp_rx_feeds_the_callers_framer(harness):
+    """_Z10m17_dsp_rxP6scmplxi, the entry m17_tx_rx.cpp:164-165 calls once per 40 ms block: 24 blocks
+    through front end + timing recovery on the GPU, symbols handed to the caller's m17_rx_symbols, the
+    loop threshold taken from the caller's m17_rx_lock() (scripted: locked for blocks 6..17).  The oracle
+    runs the same stages with the same lock flag (m17_dsp.cpp:461-476, m17_rx_sync.cpp:92-95)."""
+    import m17_sdr_amd as m
+    nblk, lock_from, lock_until = 24, 6, 18
+    iq = m.generate_channel(0x4D313777, nblk, n_stream_frames=16, delay=777, ebn0_db=14.0)[0]
+    got = np.zeros(nblk * 193 + 8, np.float32)
+    counts = np.zeros(nblk, np.int32)
+    n = harness.harness_run(oracle.vp(iq), nblk, lock_from, lock_until, oracle.vp(got), got.size, oracle.vp(counts), 1)
+    assert n > 0
+    ch = oracle.Channels(1)
+    flock = ch.buf.view(np.int32)[:, 41]                 # m_flock of the oracle's channel state (tests/oracle.py)
+    want, wn = [], []
+    for b in range(nblk):
+        d, _, _ = oracle.frontend(iq[b], ch.buf[0])
+        flock[0] = 1 if lock_from <= b < lock_until else 0
+        out = np.zeros(200, np.float32)
+        k = oracle.L().m17o_rx_sync_samples(oracle.vp(ch.buf[0]), oracle.vp(d), oracle.vp(out[4:]), 384)
+        wn.append(k)
+        want.append(out[4:4 + k].copy())
+    np.testing.assert_array_equal(counts, wn)
+    np.testing.assert_array_equal(got[:n].view(np.uint32), np.concatenate(want).view(np.uint32))
+    assert set(wn) <= {191, 192, 193} and n == sum(wn)
+    # a block of another length is refused without aborting the process (the reference has no error path)
+    dsp_rx = getattr(C.CDLL(os.path.join(ROOT, "m17_sdr_amd", "libm17compat.so")), "_Z10m17_dsp_rxP6scmplxi")
+    dsp_rx(oracle.vp(iq), 960)
+
+
+def test_shim_functions_match_oracle(harness):
+    import m17_sdr_amd as m
     S = C.CDLL(os.path.join(ROOT, "m17_sdr_amd", "libm17compat.so"))
     for init in ("_Z12m17_crc_initv", "_Z13m17_init_convv", "_Z21m17_init_de_correlatev", "_Z12m17_dsp_initv",
                  "_Z14m17_golay_initv", "_Z16m17_rx_sync_initv"):

@@ -162,9 +162,9 @@ def test_exact_arithmetic_selftest():
 
 
 @pytest.mark.parametrize("options", [
-    {"sync_impl": 2}, {"sync_impl": 4, "lanes_per_channel": 64}, {"sync_impl": 4, "lanes_per_channel": 32},
-    {"sync_impl": 4, "lanes_per_channel": 16}, {"sync_impl": 5, "lanes_per_channel": 64}, {"sync_impl": 6}, {"sync_impl": 6, "lanes_per_channel": 32}, {"sync_impl": 5, "lanes_per_channel": 32},
-    {"sync_impl": 5, "lanes_per_channel": 16}, {"decode_impl": 0}, {"decode_impl": 1}, {"decode_impl": 2}, {"fe_impl": 1}, {"fe_impl": 2}])
+    {"sync_impl": 4, "lanes_per_channel": 64}, {"sync_impl": 4, "lanes_per_channel": 32},
+    {"sync_impl": 4, "lanes_per_channel": 16}, {"sync_impl": 6}, {"sync_impl": 6, "lanes_per_channel": 32},
+    {"fe_impl": 1}, {"fe_impl": 2}])
 def test_every_kernel_variant_is_bit_exact(options):
     _rx_compare(C=40, nblk=22, mode=1, ebn0=200.0, nsf=12, options=options)
     _rx_compare(C=40, nblk=9, mode=1, ebn0=9.0, nsf=5, calls=3, options=options)
@@ -204,6 +204,52 @@ def test_config3_1024_channels_full_chain_bit_exact():
     compared with the CPU oracle."""
     delivered, _ = _rx_compare(C=1024, nblk=24, mode=1, ebn0=200.0, nsf=16)
     assert delivered > 1024 * 8
+
+
+def test_config2_1024_channels_front_end_bit_exact():
+    """BASELINE configs[1]: 1,024 channels on one GPU, RRC FIR + timing recovery + sync correlator only
+    (mode 0), default kernel selection (two-wave timing kernel at this size): every recovered symbol
+    and every framer record of every channel against the oracle, noiseless and with channel noise."""
+    _rx_compare(C=1024, nblk=25, mode=0, ebn0=200.0, nsf=16)
+    _rx_compare(C=1024, nblk=10, mode=0, ebn0=7.0, nsf=6)
+
+
+@pytest.mark.parametrize("ebn0", [4.0, 8.0, 12.0])
+def test_config4_16384_channels_awgn_bit_exact(ebn0):
+    """BASELINE configs[3] at its real size: 16,384 channels on one GPU, band-limited AWGN, signal from
+    the device generator (every channel distinct), DEFAULT options -- so the 16-lanes-per-channel
+    timing kernel (k_sync_frame_grp<16>, chosen above 4,096 channels) and the four-lane front end run
+    at the size the bench runs them.  EVERY channel's symbols, symbol counts, records and end state
+    are compared with the oracle (m17_rx_sync.cpp:77-99, m17_rx_frame.cpp:126-177 and the decode chain)."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    C, nblk = 16384, 12
+    rx = m.Receiver(C, nblk)
+    sig = rx.gen_batch(nblk, n_stream_frames=6, ebn0_db=ebn0, noise_cutoff_hz=6250.0)
+    out = rx.rx_blocks(sig["iq"], 1, rx.alloc_outputs(nblk, want_syms=True))
+    torch.cuda.synchronize()
+    iq = sig["iq"].cpu().numpy()
+    och = oracle.Channels(C)
+    ref = och.rx_blocks(iq, mode=1, nthreads=16)
+    counts = out["counts"].cpu().numpy()
+    np.testing.assert_array_equal(counts, ref["counts"])
+    np.testing.assert_array_equal(out["nsyms"].cpu().numpy(), ref["nsyms"])
+    np.testing.assert_array_equal(out["syms"].cpu().numpy().view(np.uint32), ref["syms"].view(np.uint32))
+    recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
+    cap = recs.shape[1]
+    assert counts.max() <= cap
+    valid = np.arange(cap)[None, :] < counts[:, None]                 # compare exactly the records that exist
+    g = recs.view(np.uint8).reshape(C, cap, 64)[valid]
+    r = ref["recs"].view(np.uint8).reshape(C, cap, 64)[valid]
+    bad = np.nonzero((g != r).any(axis=1))[0]
+    assert bad.size == 0, (bad[:5], g[bad[:1]], r[bad[:1]])
+    np.testing.assert_array_equal(rx.lock(), (och.field("m_flock") != 0).astype(np.uint8))
+    np.testing.assert_array_equal(rx.lsf(), och.field("m_lsf"))
+    np.testing.assert_array_equal(rx.counters(), och.field("counters"))
+    # the sweep means something: frames are decoded, more of them cleanly as Eb/N0 rises
+    parsed = int(((recs["flags"][valid] & m.F_PARSED) != 0).sum())
+    assert parsed > (C if ebn0 >= 8.0 else 0), parsed
+    rx.close()
 
 
 def test_large_batch_split_call_property():
@@ -310,14 +356,88 @@ def test_hostile_input_zero_saturated_and_noise():
 
 
 def test_record_capacity_overflow_and_max_blocks():
-    """More framer events than rec_cap: the count keeps running, the first rec_cap records are
-    kept; and one channel at the context's full block count."""
+    """Front-end mode with more framer events than rec_cap: the count keeps running, the first rec_cap
+    records are kept, and the carried state is unaffected (a second call still matches the oracle).
+    Full-chain mode refuses a capacity that could drop an event (its frame would miss the LICH /
+    counter bookkeeping); and one channel at the context's full block count."""
+    torch = _torch()
     import m17_sdr_amd as m
-    sig = m.generate_batch(6, 20, n_stream_frames=40, ebn0_db=200.0)
-    counts, _ = _compare_raw(np.ascontiguousarray(sig["iq"]), mode=1, rec_cap=5)
+    sig = m.generate_batch(6, 40, n_stream_frames=40, ebn0_db=200.0)
+    counts, _ = _compare_raw(np.ascontiguousarray(sig["iq"][:, :20]), mode=0, rec_cap=5)
     assert counts.max() > 5
+    # two calls with overflow in the first: framer / timing state must carry on exactly
+    rx = m.Receiver(6, 20)
+    och = oracle.Channels(6)
+    for k in range(2):
+        part = np.ascontiguousarray(sig["iq"][:, 20 * k:20 * (k + 1)])
+        cap = 5 if k == 0 else None
+        out = rx.rx_blocks(torch.from_numpy(part).cuda(), 0, rx.alloc_outputs(20, rec_cap=cap, want_syms=True))
+        torch.cuda.synchronize()
+        ref = och.rx_blocks(part, mode=0, cap=cap)
+        np.testing.assert_array_equal(out["counts"].cpu().numpy(), ref["counts"])
+        np.testing.assert_array_equal(out["syms"].cpu().numpy().view(np.uint32), ref["syms"].view(np.uint32))
+        recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(6, -1)
+        for c in range(6):
+            n = min(ref["counts"][c], recs.shape[1])
+            assert recs[c, :n].tobytes() == ref["recs"][c, :n].tobytes()
+    np.testing.assert_array_equal(rx.lock(), (och.field("m_flock") != 0).astype(np.uint8))
+    with pytest.raises(RuntimeError, match="rec_cap"):
+        rx.rx_blocks(torch.from_numpy(part).cuda(), 1, rx.alloc_outputs(20, rec_cap=5))
+    rx.close()
     sig = m.generate_batch(1, 64, n_stream_frames=70, ebn0_db=12.0)
     _compare_raw(np.ascontiguousarray(sig["iq"]), mode=1)
+
+
+def test_set_option_rejects_unknown_and_out_of_range_values():
+    """No wrong-result or retired mode is reachable from the shipped library."""
+    _torch()
+    import m17_sdr_amd as m
+    rx = m.Receiver(2, 2)
+    for name, value in (("fe_impl", 101), ("fe_impl", 107), ("fe_impl", -1), ("fe_impl", 3), ("sync_impl", 2),
+                        ("sync_impl", 5), ("sync_impl", 0), ("lanes_per_channel", 8), ("lanes_per_channel", 48),
+                        ("decode_impl", 0), ("no_such_option", 1)):
+        with pytest.raises(RuntimeError):
+            rx.set_option(name, value)
+    for name, value in (("fe_impl", 0), ("fe_impl", 1), ("fe_impl", 2), ("sync_impl", 4), ("sync_impl", 6),
+                        ("lanes_per_channel", 0), ("lanes_per_channel", 16)):
+        rx.set_option(name, value)
+    rx.close()
+
+
+def test_sync_samples_stage_entry_leaves_framer_state_alone():
+    """m17gpu_sync_samples (m17_rx_sync_samples with an external lock flag) followed by rx_blocks on
+    the same context: only the timing state may have advanced -- the oracle does the same two steps."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    Cn, nblk = 12, 6
+    sig = m.generate_batch(Cn, 2 * nblk, n_stream_frames=10, ebn0_db=15.0)
+    rx = m.Receiver(Cn, nblk)
+    och = oracle.Channels(Cn)
+    first = np.ascontiguousarray(sig["iq"][:, :nblk]); second = np.ascontiguousarray(sig["iq"][:, nblk:])
+    # stage 1 on both sides: front end of the first half, then timing recovery alone under lock = 0
+    disc, _ = rx.frontend(torch.from_numpy(first).cuda())
+    syms, nsyms = rx.sync_samples(disc, lock=False)
+    torch.cuda.synchronize()
+    want = np.zeros((Cn, nblk * 193 + 8), np.float32); wn = np.zeros((Cn, nblk), np.int32)
+    for c in range(Cn):
+        pos = 0
+        for b in range(nblk):
+            d, _, _ = oracle.frontend(first[c, b], och.buf[c])
+            out = np.zeros(200, np.float32)
+            n = oracle.L().m17o_rx_sync_samples(oracle.vp(och.buf[c]), oracle.vp(d), oracle.vp(out[4:]), 384)
+            wn[c, b] = n; want[c, pos:pos + n] = out[4:4 + n]; pos += n
+    np.testing.assert_array_equal(nsyms.cpu().numpy(), wn)
+    np.testing.assert_array_equal(syms.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # stage 2: the full receive call on the second half must continue from exactly that state
+    out = rx.rx_blocks(torch.from_numpy(second).cuda(), 1, rx.alloc_outputs(nblk, want_syms=True))
+    torch.cuda.synchronize()
+    ref = och.rx_blocks(second, mode=1)
+    np.testing.assert_array_equal(out["counts"].cpu().numpy(), ref["counts"])
+    np.testing.assert_array_equal(out["syms"].cpu().numpy().view(np.uint32), ref["syms"].view(np.uint32))
+    recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(Cn, -1)
+    for c in range(Cn):
+        assert recs[c, :ref["counts"][c]].tobytes() == ref["recs"][c, :ref["counts"][c]].tobytes()
+    rx.close()
 
 
 @pytest.mark.parametrize("ebn0,cutoff", [(200.0, 0.0), (9.0, 0.0), (8.0, 6250.0)])
@@ -350,8 +470,7 @@ def test_gpu_signal_source_matches_host_generator(ebn0, cutoff):
     rx.close()
 
 
-@pytest.mark.parametrize("decode_impl", [1, 2])
-def test_stage_decode_frames_mixed_types_and_golay(decode_impl):
+def test_stage_decode_frames_mixed_types_and_golay():
     """m17gpu_decode_frames (the stateless part of m17_rx_parse) on a shuffled batch of link-setup,
     stream and packet frames with noise, against the oracle frame by frame; m17gpu_golay_decode on
     random 24-bit words."""
@@ -379,7 +498,6 @@ def test_stage_decode_frames_mixed_types_and_golay(decode_impl):
         a = np.float32(rng.uniform(0.05, 2.0))
         sym[i] = a * level[d & 3] + a * np.float32(rng.choice([0.0, 0.15, 0.6])) * rng.standard_normal(192).astype(np.float32)
     rx = m.Receiver(4, 2)
-    rx.set_option("decode_impl", decode_impl)
     got = rx.decode_frames(torch.from_numpy(sym).cuda(), torch.from_numpy(types).cuda()).cpu().numpy().view(oracle.REC_DTYPE).reshape(-1)
     for i in range(n):
         ch = oracle.Channels(1)
