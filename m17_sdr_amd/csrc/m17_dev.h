@@ -79,6 +79,7 @@ static_assert(sizeof(ChanState) == 1920, "ChanState layout");
 struct DevTables {
     float    mf[kPhases][32];        // matched filter taps, 31 used
     float    md[kPhases][32];        // derivative filter taps
+    float    tap_pairs[kPhases][64]; // the same taps as (matched, derivative) pairs, 32 pairs per branch (pair 31 = 0)
     int16_t  gather[4][488];         // -1 erasure, else src | 0x4000 when negated
     int16_t  lich[96];
     int16_t  glen[4];

@@ -104,6 +104,39 @@ __device__ __forceinline__ v2f fir_pair(const float *xs, const float4 (&tp)[16])
     return acc + (v2f){xl, xl} * (v2f){tp[15].x, tp[15].y};
 }
 
+// ---- lane-group primitives on DPP rows (a row is 16 lanes; LPC is 16, 32 or 64) -------------------
+template <int CTRL, int ROWMASK = 0xF>
+__device__ __forceinline__ int dpp_add_i(int acc, int v)            // acc + (v moved by CTRL, 0 where no source lane)
+{
+    return acc + __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, true);
+}
+// inclusive prefix sum over the LPC lanes of every group
+template <int LPC>
+__device__ __forceinline__ int group_scan_incl(int v)
+{
+    v = dpp_add_i<0x111>(v, v);          // row_shr:1
+    v = dpp_add_i<0x112>(v, v);          // row_shr:2
+    v = dpp_add_i<0x114>(v, v);          // row_shr:4
+    v = dpp_add_i<0x118>(v, v);          // row_shr:8
+    if (LPC >= 32) v = dpp_add_i<0x142, 0xA>(v, v);      // row_bcast:15 into rows 1 and 3
+    if (LPC == 64) v = dpp_add_i<0x143, 0xC>(v, v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// the value held by the LAST lane of each group, in every lane of the group (LDS crossbar, no memory)
+template <int LPC>
+__device__ __forceinline__ int group_bcast_last_i(int v)
+{
+    if (LPC == 64) return __builtin_amdgcn_readlane(v, 63);
+    // ds_swizzle bit mode: lane' = ((lane & and) | or) ^ xor inside each 32-lane half
+    if (LPC == 32) return __builtin_amdgcn_ds_swizzle(v, 0x1F << 5);               // and 0, or 31
+    return __builtin_amdgcn_ds_swizzle(v, 0x10 | (0x0F << 5));                      // and 16, or 15
+}
+template <int LPC>
+__device__ __forceinline__ float group_bcast_last_f(float v)
+{
+    return __int_as_float(group_bcast_last_i<LPC>(__float_as_int(v)));
+}
+
 // One pass of the timing loop over up to W*LPC instants starting at input p (clk == 0 on
 // entry): W independent FIR chains per lane, then the vote ticks in time order (sync_update
 // m17_rx_sync.cpp:38-42, m17_sync_adjust :45-72).  The first threshold crossing ends the pass.
@@ -119,6 +152,29 @@ __device__ __forceinline__ void timing_pass(GrpChan &my, const float4 (&tp)[16],
         const int inst = gl + LPC * j;
         const v2f a = fir_pair(my.x + p + 2 * (inst < rem ? inst : 0), tp);
         s[j] = a.x; d[j] = a.y;
+    }
+    if (W == 1) {
+        // Fast path, the common case while a channel tracks: a full round, every group of the wave stays inside
+        // its threshold.  The vote counter after each tick is a prefix sum over the group's lanes (DPP row
+        // operations), no ballots, no per-group mask shifts.  Anything else -- a crossing in any group of the
+        // wave, a partial round behind a crossing, the symbol index at -1 after a downward wrap -- takes the
+        // general path below with the same s / d.
+        const bool vote_ok = (p + 2 * gl + 1 < kDiscOut);
+        const float dd = (s[0] < 0.0f) ? -d[0] : d[0];              // sync_update, m17_rx_sync.cpp:38-42
+        int v = (dd > 0.0f) ? 1 : ((dd < 0.0f) ? -1 : 0);
+        v = vote_ok ? v : 0;
+        const int t = thr + group_scan_incl<LPC>(v);
+        const bool general = (rem < LPC) | (m_idx < 0) | (t > thresh) | (t < -thresh);
+        if (__builtin_amdgcn_ballot_w64(general) == 0ull) {
+            my.h[8 + m_idx + gl] = s[0];
+            m_idx += LPC;
+            thr = group_bcast_last_i<LPC>(t);
+            sum = group_bcast_last_f<LPC>(s[0]);
+            dif = group_bcast_last_f<LPC>(d[0]);
+            if (p + 2 * LPC - 1 < kDiscOut) { clk = 0; p += 2 * LPC; }
+            else { clk = 1; p = kDiscOut; }                         // the last vote tick falls into the next block
+            return;
+        }
     }
     bool crossed = false;
     int ts = 0, kcross = 0;
