@@ -106,6 +106,24 @@ __device__ __forceinline__ SyncResult sync_check_wave(const float v[8])
     return r;
 }
 
+// wave-wide max / min of a per-lane int on DPP row operations
+template <int CTRL, int RM = 0xF> __device__ __forceinline__ int dpp_keep(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xF, false);      // lanes without a source keep their own value
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+    v = max(v, dpp_keep<0x111>(v)); v = max(v, dpp_keep<0x112>(v)); v = max(v, dpp_keep<0x114>(v)); v = max(v, dpp_keep<0x118>(v));
+    v = max(v, dpp_keep<0x142, 0xA>(v)); v = max(v, dpp_keep<0x143, 0xC>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min_i(int v)
+{
+    v = min(v, dpp_keep<0x111>(v)); v = min(v, dpp_keep<0x112>(v)); v = min(v, dpp_keep<0x114>(v)); v = min(v, dpp_keep<0x118>(v));
+    v = min(v, dpp_keep<0x142, 0xA>(v)); v = min(v, dpp_keep<0x143, 0xC>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // One symbol instant: the matched (s) and derivative (d) 31-tap dot products over the
 // delay line xs[0..30], strictly in the reference's order (rx_sync_filter,
 // m17_rx_sync.cpp:25-31: bare first product, then += in ascending tap order, separate

@@ -5,7 +5,6 @@
 #include "m17_sync_common.hip"
 #include "m17_sync_grp.hip"
 #include "m17_sync_duo.hip"
-#include "m17_sync_blk.hip"
 #include "m17_decode_quad.hip"
 #include "m17_book.hip"
 #include "m17_pluto.hip"
@@ -158,13 +157,7 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
     // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
     int lpc = ctx->lanes_per_channel;
     if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
-    if (ctx->sync_impl == 10 && ext_lock < 0 && ctx->lanes_per_channel == 0) {
-        // one wave per channel, a whole block per pass (m17_sync_blk.hip)
-        hipLaunchKernelGGL(k_sync_frame_blk, dim3(cdiv(ctx->C, BLK_WAVES)), dim3(64 * BLK_WAVES), 0, st,
-                           disc, offs, ctx->d_state, ctx->C, nblk, mode,
-                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
-                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms, ctx->d_fsym, b0, bcount);
-    } else if (ctx->sync_impl == 6 && ext_lock < 0 && lpc == 64 && ctx->C <= 1024) {
+    if (ctx->sync_impl == 6 && ext_lock < 0 && lpc == 64 && ctx->C <= 1024) {
         // timing wave + framer wave per channel (m17_sync_duo.hip): one 8-wave workgroup per CU.  Beyond 1,024
         // channels a second workgroup per CU does not fit its registers and the lane-group kernel wins (2,048 x 50:
         // 0.350 vs 0.288 ms); the lock-forced stage entry has no framer and uses the lane-group kernel too
@@ -360,7 +353,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
     auto bad = [&]() { return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: value out of range for ") + name); };
-    if (!std::strcmp(name, "sync_impl")) { if (value != 4 && value != 6 && value != 10) return bad(); ctx->sync_impl = value; }
+    if (!std::strcmp(name, "sync_impl")) { if (value != 4 && value != 6) return bad(); ctx->sync_impl = value; }
     else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 2) return bad(); ctx->fe_impl = value; }
     else if (!std::strcmp(name, "lanes_per_channel")) {
         if (value != 0 && value != 16 && value != 32 && value != 64) return bad();

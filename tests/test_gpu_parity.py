@@ -163,7 +163,7 @@ def test_exact_arithmetic_selftest():
 
 @pytest.mark.parametrize("options", [
     {"sync_impl": 4, "lanes_per_channel": 64}, {"sync_impl": 4, "lanes_per_channel": 32},
-    {"sync_impl": 4, "lanes_per_channel": 16}, {"sync_impl": 6}, {"sync_impl": 10}, {"sync_impl": 6, "lanes_per_channel": 32},
+    {"sync_impl": 4, "lanes_per_channel": 16}, {"sync_impl": 6}, {"sync_impl": 6, "lanes_per_channel": 32},
     {"fe_impl": 1}, {"fe_impl": 2}])
 def test_every_kernel_variant_is_bit_exact(options):
     _rx_compare(C=40, nblk=22, mode=1, ebn0=200.0, nsf=12, options=options)
