@@ -30,6 +30,8 @@ namespace m17dev {
 
 __constant__ DevTables c_tab;
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // ---------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------

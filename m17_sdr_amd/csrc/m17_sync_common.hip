@@ -129,7 +129,6 @@ __device__ __forceinline__ int wave_min_i(int v)
 // m17_rx_sync.cpp:25-31: bare first product, then += in ascending tap order, separate
 // multiply and add).  31 taps in four groups of 8 (last: 7); the next group's LDS reads
 // (taps are wave-uniform broadcasts) are issued before the current group's chain.
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 // tp4: the branch's 32 (matched, derivative) tap pairs = 16 float4 (md4 is unused: kept for call compatibility)
 __device__ __forceinline__ void fir_instant(const float *xs, const float4 *tp4, const float4 *, float &s, float &d)
