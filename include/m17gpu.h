@@ -146,7 +146,13 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  *                            channel at every size
  *   "lanes_per_channel"  0 = by channel count (default) | 16 | 32 | 64 (lane-group kernel)
  *   "fe_impl"            0 = by size (default), 1 = lane per channel-block, 2 = four lanes per
- *                            channel-block */
+ *                            channel-block
+ * and one functional switch:
+ *   "afc"                0 (default, as the reference ships: radio.cpp:8) | 1 = radio_set_afc_on(): the
+ *                            NCO mixer of m17_dsp.cpp:390-408,468 with the loop of radio.cpp:196-208 per channel.
+ *                            The correction closes a loop over the whole chain, so an AFC context is processed
+ *                            block by block; its double-precision cos/sin make this the one path held to
+ *                            tolerance parity (same payloads, correction within 1e-4) instead of bit parity. */
 int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value);
 
 /* ---------------- measurement hooks ---------------- */
@@ -170,6 +176,8 @@ int m17gpu_selftest(m17gpu_ctx *ctx, unsigned *h_bad);
 int m17gpu_get_lsf(m17gpu_ctx *ctx, uint8_t *h_lsf /* [C][2][30] */);
 /* g_errors, n_frames, in_frame, frame_id_epoch per channel (m17_dbase.cpp:60-82) */
 int m17gpu_get_counters(m17gpu_ctx *ctx, uint32_t *h_cnt /* [C][4] */);
+/* m_afc_delta of every channel (radio.cpp:10), radians per sample; 0 while AFC is off or outside a frame */
+int m17gpu_get_afc(m17gpu_ctx *ctx, float *h_delta /* [C] */);
 /* m17_rx_lock() of every channel (m17_rx_frame.cpp:187-189) */
 int m17gpu_get_lock(m17gpu_ctx *ctx, uint8_t *h_lock /* [C] */);
 /* host copies of the uploaded tables, for inspection / tests */

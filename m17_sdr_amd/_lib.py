@@ -62,6 +62,7 @@ SIGNATURES = {
     "m17gpu_get_lsf": (_i, [_vp, _vp]),
     "m17gpu_get_counters": (_i, [_vp, _vp]),
     "m17gpu_get_lock": (_i, [_vp, _vp]),
+    "m17gpu_get_afc": (_i, [_vp, _vp]),
     "m17gpu_get_taps": (_i, [_vp, _vp]),
     "m17gpu_get_golay_tables": (_i, [_vp, _vp]),
     "m17gpu_get_constant": (_i, [C.c_char_p, _vp, _i]),

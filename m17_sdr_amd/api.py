@@ -233,6 +233,11 @@ class Receiver:
         _check(lib().m17gpu_get_counters(self._ctx, a.ctypes.data_as(C.c_void_p)), "m17gpu_get_counters")
         return a
 
+    def afc_delta(self):
+        a = np.zeros((self.C,), np.float32)
+        _check(lib().m17gpu_get_afc(self._ctx, a.ctypes.data_as(C.c_void_p)), "m17gpu_get_afc")
+        return a
+
     def lock(self):
         a = np.zeros((self.C,), np.uint8)
         _check(lib().m17gpu_get_lock(self._ctx, a.ctypes.data_as(C.c_void_p)), "m17gpu_get_lock")

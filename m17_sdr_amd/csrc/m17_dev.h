@@ -66,7 +66,9 @@ struct ChanState {
     uint32_t g_errors, n_frames, in_frame, frame_id_epoch;
     int32_t  packet_idx;                                  // m17_rx_parse.cpp:7
     int32_t  sym_total;                                   // symbols emitted so far in the current call (pipelined launches)
-    int32_t  pad[13];
+    float    afc_delta;                                   // m_afc_delta                 radio.cpp:10   (AFC contexts only)
+    double   afc_acc;                                     // NCO phase of dsp_nco_mixer  m17_dsp.cpp:391
+    int32_t  pad[10];
     float    buff[32];                                    // m_buff[31]           m17_rx_sync.cpp:11
     float    sync[8];                                     // m_sync               m17_rx_frame.cpp:104
     float    fsym[kFrameSyms];                            // m_f_sym              m17_rx_frame.cpp:14

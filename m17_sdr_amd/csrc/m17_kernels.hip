@@ -428,6 +428,71 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_frontend_afc: the front end of ONE block with the AFC branch taken (m17_dsp.cpp:468): dsp_nco_mixer
+// (:390-408) between conversion and limiter, radio_get_afc_delta / radio_afc (radio.cpp:196-208) around it.
+// AFC closes a loop through the whole chain -- the correction applied to block b comes from the DC estimate of
+// block b-1 and is gated by the framer's in-frame flag after block b-1 (m17_aos / m17_los, m17_dbase.cpp:60-75,
+// which is the lock flag) -- so blocks cannot be taken in parallel: m17gpu_rx_blocks runs this kernel and the
+// timing / framer kernel once per block when the context has AFC on.  One wave per channel.
+// The NCO phase of sample i is acc + i * delta in double (the reference adds delta i times: the two differ by
+// rounding noise of ~1e-13 rad), cos / sin come from the device's double library: results agree with the
+// reference to the last place except where a cosine lands on a float rounding boundary, so this path is held
+// to tolerance parity (identical decoded payloads, correction trace within 1e-4), not bit parity.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64)
+void k_frontend_afc(const uint32_t *__restrict__ iq,      // [C][nblk][1920] packed (re | im << 16)
+                    ChanState *__restrict__ st, float *__restrict__ disc_raw, float *__restrict__ offs,
+                    int nblk, int b)
+{
+    __shared__ float2 z[kBlockSamples + 2];               // limited samples, the two before the block in front
+    __shared__ float uh[kBlockSamples];
+    const int lane = lane_id(), chan = (int)blockIdx.x;
+    ChanState &cs = st[chan];
+    const size_t row = (size_t)chan * nblk + b;
+    const bool in_frame = uni(cs.flock) != 0;             // m17_db_in_frame(): set by m17_aos, cleared by m17_los
+    const float delta = in_frame ? unif(cs.afc_delta) : 0.0f;     // radio_get_afc_delta(): dropped outside a frame
+    const double acc0 = cs.afc_acc;
+    if (lane == 0) { z[0] = make_float2(cs.z1re, cs.z1im); z[1] = make_float2(cs.z0re, cs.z0im); }
+    for (int i = lane; i < kBlockSamples; i += 64) {
+        const uint32_t w = iq[row * kBlockSamples + i];
+        float re = s16_to_float((int)(short)(w & 0xFFFF)), im = s16_to_float((int)w >> 16);
+        const double a = acc0 + (double)i * (double)delta;
+        const float c = (float)cos(a), s = (float)sin(a);
+        const float mre = (re * c) - (im * s);
+        const float mim = (re * s) + (im * c);
+        re = mre; im = mim;
+        limit(re, im);
+        z[2 + i] = make_float2(re, im);
+    }
+    __syncthreads();
+    for (int i = lane; i < kBlockSamples; i += 64) {
+        const float2 x = z[2 + i], z0 = z[1 + i], z1 = z[i];
+        const float a = z0.y * (x.x - z1.x);               // dsp_arctan_disc2 (m17_dsp.cpp:194-222)
+        const float bb = z0.x * (x.y - z1.y);
+        uh[i] = (bb - a) * 0.5f;
+    }
+    __syncthreads();
+    for (int k = lane; k < kDiscOut; k += 64) disc_raw[row * kDiscOut + k] = uh[5 * k + 4];
+    if (lane == 0) {
+        float offset = 0.0f;
+        double acc = acc0;
+        for (int i = 0; i < kBlockSamples; ++i) { offset += uh[i]; acc += (double)delta; }   // both strictly sequential
+        offset = offset / (float)kBlockSamples;
+        offs[row] = offset;
+        double ip;
+        acc = acc / (2.0 * 3.14159265358979323846);        // :402-407
+        acc = modf(acc, &ip);
+        acc = acc * 2.0 * 3.14159265358979323846;
+        if (acc != acc) acc = 0.0;
+        cs.afc_acc = acc;
+        // radio_afc(offset): float m_afc_delta, double arithmetic (radio.cpp:196-200)
+        cs.afc_delta = in_frame ? (float)((double)delta - (double)offset * 0.1) : 0.0f;
+        const float2 l0 = z[kBlockSamples + 1], l1 = z[kBlockSamples];
+        cs.z0re = l0.x; cs.z0im = l0.y; cs.z1re = l1.x; cs.z1im = l1.y;
+    }
+}
+
 // out[i] -= offset (m17_dsp.cpp:217-219) for the stand-alone front-end entry point
 __global__ void k_dc_remove(float *__restrict__ disc, const float *__restrict__ offs, int total)
 {

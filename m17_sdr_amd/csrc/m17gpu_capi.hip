@@ -35,6 +35,7 @@ struct m17gpu_ctx {
     int32_t *d_work = nullptr, *d_nwork = nullptr, *d_counts = nullptr;
     uint16_t *d_genc = nullptr, *d_gerr = nullptr, *d_crc_basis = nullptr;
     uint32_t *d_dec_hist = nullptr;          // [C][32] history of the wide-band decimator
+    int afc = 0;                             // 1 = AFC on (radio_set_afc_on): block-sequential front end
     int lanes_per_channel = 0;               // lane-group timing kernel: 0 = by channel count, else 16 | 32 | 64
     bool profiling = false;
     int fe_impl = 0;                         // 0 = by size (four lanes per channel-block), 1 = lane per channel-block, 2 = four lanes
@@ -281,11 +282,24 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
     // (Overlapping chunked front-end launches with the timing kernel on a second stream was
     //  measured and dropped: 477 us vs 390 us per step at 1,024 x 50 -- the small launches lose
     //  more occupancy than the overlap hides.  Both kernels still accept a block range.)
-    if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, st)) != M17GPU_OK) return rc;
-    MARK(1);
-    if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
-                                d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
-    MARK(2);
+    if (ctx->afc) {
+        // AFC closes a per-block loop through front end, timing loop and framer (k_frontend_afc): block by block
+        for (int b = 0; b < nblk; ++b) {
+            hipLaunchKernelGGL(k_frontend_afc, dim3(ctx->C), dim3(64), 0, st, reinterpret_cast<const uint32_t *>(d_iq),
+                               ctx->d_state, ctx->d_disc, ctx->d_offs, nblk, b);
+            HIPCHK(hipGetLastError());
+            if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
+                                        d_syms, d_nsyms, st, -1, b, 1)) != M17GPU_OK) return rc;
+        }
+        MARK(1);
+        MARK(2);
+    } else {
+        if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, st)) != M17GPU_OK) return rc;
+        MARK(1);
+        if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
+                                    d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
+        MARK(2);
+    }
     if ((mode & 0xFF) == 1) {
         int32_t *cnt = d_counts ? d_counts : ctx->d_counts;
         const long long slots = (long long)ctx->C * rec_cap;
@@ -359,6 +373,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
         if (value != 0 && value != 16 && value != 32 && value != 64) return bad();
         ctx->lanes_per_channel = value;
     }
+    else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
     else return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: unknown option ") + name);
     return M17GPU_OK;
 }
@@ -584,6 +599,15 @@ int m17gpu_get_counters(m17gpu_ctx *ctx, uint32_t *h_cnt)
         h_cnt[4 * c + 0] = h[c].g_errors; h_cnt[4 * c + 1] = h[c].n_frames;
         h_cnt[4 * c + 2] = h[c].in_frame; h_cnt[4 * c + 3] = h[c].frame_id_epoch;
     }
+    return M17GPU_OK;
+}
+
+int m17gpu_get_afc(m17gpu_ctx *ctx, float *h_delta)
+{
+    if (!ctx || !h_delta) return fail(M17GPU_ERR_ARG, "m17gpu_get_afc: bad argument");
+    ON_CTX_DEVICE(ctx);
+    std::vector<ChanState> h; int rc = fetch_state(ctx, h); if (rc) return rc;
+    for (int c = 0; c < ctx->C; ++c) h_delta[c] = h[c].afc_delta;
     return M17GPU_OK;
 }
 

@@ -464,9 +464,25 @@ void m17o_frontend(m17o_chan *st, const int16_t *iq, float *d, float *d_raw, flo
     int idx = 0;
     float z0re = st->z0re, z0im = st->z0im, z1re = st->z1re, z1im = st->z1im;
     int count = st->disc_count;
+    /* AFC, only when switched on (m17_dsp.cpp:468): radio_get_afc_delta() radio.cpp:201-208 -- outside a
+     * frame the correction is dropped; dsp_nco_mixer m17_dsp.cpp:390-408 with its static double phase */
+    float delta = 0;
+    double acc = st->afc_acc;
+    if (st->afc_on) {
+        if (st->in_frame) delta = st->afc_delta;
+        else st->afc_delta = 0;
+    }
     for (int i = 0; i < M17O_BLOCK_SAMPLES; i++) {
         float re = (float)((double)iq[2 * i] * 0.00003);
         float im = (float)((double)iq[2 * i + 1] * 0.00003);
+        if (st->afc_on) {
+            float c = (float)cos(acc);
+            float s = (float)sin(acc);
+            acc += delta;
+            float mre = (re * c) - (im * s);
+            float mim = (re * s) + (im * c);
+            re = mre; im = mim;
+        }
         float m = sqrtf(re * re + im * im);
         float g = (float)(1.0 / (double)m);
         re = re * g;
@@ -480,13 +496,26 @@ void m17o_frontend(m17o_chan *st, const int16_t *iq, float *d, float *d_raw, flo
         if (count == 0) d[idx++] = u * 0.5f;
         offset += u * 0.5f;
     }
+    if (st->afc_on) {
+        double ip;
+        acc = acc / (2.0 * M_PI);               /* :402-407 */
+        acc = modf(acc, &ip);
+        acc = acc * 2.0 * M_PI;
+        if (acc != acc) acc = 0;
+        st->afc_acc = acc;
+    }
     st->z0re = z0re; st->z0im = z0im; st->z1re = z1re; st->z1im = z1im;
     st->disc_count = count;
     if (d_raw) memcpy(d_raw, d, sizeof(float) * (size_t)idx);
     offset = offset / M17O_BLOCK_SAMPLES;
+    /* radio_afc(offset), radio.cpp:196-200: float m_afc_delta, double arithmetic */
+    if (st->afc_on && st->in_frame) st->afc_delta = (float)((double)st->afc_delta - (double)offset * 0.1);
     for (int i = 0; i < idx; i++) d[i] = d[i] - offset;
     if (offset_out) *offset_out = offset;
 }
+
+void m17o_set_afc(m17o_chan *st, int on) { st->afc_on = on ? 1 : 0; if (!on) { st->afc_delta = 0; } }
+void m17o_get_afc(const m17o_chan *st, float *delta, double *acc) { if (delta) *delta = st->afc_delta; if (acc) *acc = st->afc_acc; }
 
 /* m17_rx_sync.cpp:25-31 */
 static float sync_filter(const float *in, const float *c)

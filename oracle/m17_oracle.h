@@ -80,6 +80,11 @@ typedef struct {
     /* bookkeeping mirrored from m17_dbase.cpp:60-82 */
     uint32_t g_errors, n_frames, in_frame, frame_id_epoch;
     uint32_t block_count;
+    /* AFC (optional, off by default like radio.cpp:8): radio.cpp:9-10 m_afc / m_afc_delta, the NCO phase of
+     * dsp_nco_mixer (m17_dsp.cpp:391).  Appended so that the offsets above stay what tests/oracle.py knows. */
+    int32_t  afc_on;
+    float    afc_delta;
+    double   afc_acc;
 } m17o_chan;
 
 /* ---- init / tables ---- */
@@ -140,6 +145,9 @@ int  m17o_rx_blocks(m17o_chan *st, int C, int nblk, const int16_t *iq,
                     m17o_rec *recs, int cap, int32_t *counts,
                     float *syms, int32_t *nsyms, int mode, int nthreads);
 int  m17o_sizeof_chan(void);
+/* AFC of one channel (radio_set_afc_on/off mmi.cpp:90-101; state radio.cpp:10, m17_dsp.cpp:391) */
+void m17o_set_afc(m17o_chan *st, int on);
+void m17o_get_afc(const m17o_chan *st, float *delta, double *acc);
 
 /* ---- wide-band ingest (radio.cpp:18-51,157-177): 31-tap symmetric /8 decimator, Q15 ---- */
 void m17o_pluto_build_dec_filter(int16_t *coffs /* [31] */);

@@ -75,6 +75,19 @@ class Channels:
                            int(mode), int(nthreads))
         return {"recs": recs, "counts": counts, "syms": syms, "nsyms": nsyms}
 
+    def set_afc(self, on=True):
+        for c in range(self.n):
+            L().m17o_set_afc(vp(self.buf[c]), int(bool(on)))
+
+    def afc(self):
+        """(m_afc_delta [n] float32, NCO phase [n] float64)"""
+        d = np.zeros(self.n, np.float32); a = np.zeros(self.n, np.float64)
+        for c in range(self.n):
+            dd, aa = C.c_float(), C.c_double()
+            L().m17o_get_afc(vp(self.buf[c]), C.byref(dd), C.byref(aa))
+            d[c], a[c] = dd.value, aa.value
+        return d, a
+
     def field(self, name):
         """Selected state fields as arrays (layout of m17o_chan in oracle/m17_oracle.h)."""
         i32 = self.buf.view(np.int32)
