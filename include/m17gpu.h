@@ -163,6 +163,9 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value);
  * then clears the record. */
 int m17gpu_set_profiling(m17gpu_ctx *ctx, int on);
 int m17gpu_get_kernel_ms(m17gpu_ctx *ctx, float h_ms[4], int *h_calls);
+/* The same, plus the average duration of a whole m17gpu_rx_blocks call between two events on the caller's stream
+ * (kernels, the gaps between them and the small memset included). */
+int m17gpu_get_call_ms(m17gpu_ctx *ctx, float h_ms[4], float *h_call_ms, int *h_calls);
 
 /* Exhaustive on-device equivalence check of the front end's shortened exact
  * arithmetic (int16 scaling of m17_dsp.cpp:136-141, sqrt and reciprocal of

@@ -58,6 +58,7 @@ SIGNATURES = {
     "m17gpu_set_option": (_i, [_vp, C.c_char_p, _i]),
     "m17gpu_set_profiling": (_i, [_vp, _i]),
     "m17gpu_get_kernel_ms": (_i, [_vp, _vp, _vp]),
+    "m17gpu_get_call_ms": (_i, [_vp, _vp, _vp, _vp]),
     "m17gpu_selftest": (_i, [_vp, _vp]),
     "m17gpu_get_lsf": (_i, [_vp, _vp]),
     "m17gpu_get_counters": (_i, [_vp, _vp]),

@@ -216,6 +216,14 @@ class Receiver:
         _check(lib().m17gpu_get_kernel_ms(self._ctx, ms, C.byref(n)), "m17gpu_get_kernel_ms")
         return list(ms), n.value
 
+    def call_ms(self):
+        """(stage ms [4], average ms of a whole rx_blocks call on the caller's stream, calls averaged)."""
+        ms = (C.c_float * 4)()
+        call = C.c_float()
+        n = C.c_int()
+        _check(lib().m17gpu_get_call_ms(self._ctx, ms, C.byref(call), C.byref(n)), "m17gpu_get_call_ms")
+        return list(ms), call.value, n.value
+
     def selftest(self):
         """Mismatch counts of the exhaustive exact-arithmetic self test (must be all zero)."""
         bad = (C.c_uint * 4)()

@@ -41,7 +41,7 @@ struct m17gpu_ctx {
     int fe_impl = 0;                         // 0 = by size (four lanes per channel-block), 1 = lane per channel-block, 2 = four lanes
     int sync_impl = 6;                       // 6 = timing wave + framer wave per channel up to 1,024 channels, lane groups beyond (default);
                                              // 4 = lane group per channel at every size
-    std::vector<hipEvent_t> ev_pool;         // 5 events per profiled call
+    std::vector<hipEvent_t> ev_pool;         // 7 events per profiled call: 5 stage marks + call start / end
     std::vector<int> ev_mode;                // mode of each profiled call
 };
 
@@ -132,29 +132,45 @@ int upload_tables(m17gpu_ctx *ctx)
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Channel range [c0, c0 + cn) of the context (cn < 0: all): every array of the path is channel-major, so a range
+// is the same launch on offset pointers.
 int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc, float *offs,
-                    int update_state, hipStream_t st, int b0 = 0, int cbk = -1)
+                    int update_state, hipStream_t st, int b0 = 0, int cbk = -1, int c0 = 0, int cn = -1)
 {
     if (cbk < 0) cbk = nblk;
-    const int total = ctx->C * cbk;
+    if (cn < 0) cn = ctx->C;
+    const int total = cn * cbk;
+    d_iq += (size_t)c0 * nblk * kBlockSamples * 2;
+    disc += (size_t)c0 * nblk * kDiscOut;
+    offs += (size_t)c0 * nblk;
+    ChanState *state = ctx->d_state + c0;
     // measured on MI355X (scripts/exp_scale.py): the 4-lane kernel wins at 51,200 .. 196,608 channel-blocks,
     // so it is the default at every size; fe_impl 1 keeps the one-lane kernel selectable
     const bool quad = ctx->fe_impl != 1;
     if (quad)
         hipLaunchKernelGGL(k_frontend_q, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st,
-                           reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, disc, offs, nblk, total, update_state, b0, cbk);
+                           reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state, b0, cbk);
     else
         hipLaunchKernelGGL(k_frontend, dim3(cdiv(total, 64 * FE_WAVES)), dim3(64 * FE_WAVES), 0, st,
-                           reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, disc, offs, nblk, total, update_state);
+                           reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
 
 int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int nblk, int mode,
                       m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, float *d_syms, int32_t *d_nsyms,
-                      hipStream_t st, int ext_lock = -1, int b0 = 0, int bcount = -1)
+                      hipStream_t st, int ext_lock = -1, int b0 = 0, int bcount = -1, int c0 = 0, int cn = -1)
 {
     if (bcount < 0) bcount = nblk;
+    if (cn < 0) cn = ctx->C;
+    disc += (size_t)c0 * nblk * kDiscOut;
+    if (offs) offs += (size_t)c0 * nblk;
+    ChanState *state = ctx->d_state + c0;
+    m17gpu_rec_dev *recs = d_recs ? reinterpret_cast<m17gpu_rec_dev *>(d_recs) + (size_t)c0 * rec_cap : nullptr;
+    int32_t *counts = (d_counts ? d_counts : ctx->d_counts) + c0;
+    float *syms = d_syms ? d_syms + (size_t)c0 * M17_SYM_STRIDE(nblk) : nullptr;
+    int32_t *nsyms = d_nsyms ? d_nsyms + (size_t)c0 * nblk : nullptr;
+    float *fsym = ctx->d_fsym + (size_t)c0 * rec_cap * kFrameSyms;
     // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
     int lpc = ctx->lanes_per_channel;
     if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
@@ -162,18 +178,40 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
         // timing wave + framer wave per channel (m17_sync_duo.hip): one 8-wave workgroup per CU.  Beyond 1,024
         // channels a second workgroup per CU does not fit its registers and the lane-group kernel wins (2,048 x 50:
         // 0.350 vs 0.288 ms); the lock-forced stage entry has no framer and uses the lane-group kernel too
-        hipLaunchKernelGGL(k_sync_frame_duo, dim3(cdiv(ctx->C, 4)), dim3(512), 0, st,
-                           disc, offs, ctx->d_state, ctx->C, nblk, mode,
-                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,
-                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms, ctx->d_fsym, b0, bcount);
+        hipLaunchKernelGGL(k_sync_frame_duo, dim3(cdiv(cn, 4)), dim3(512), 0, st,
+                           disc, offs, state, cn, nblk, mode, recs, recs ? rec_cap : 0,
+                           counts, syms, nsyms, fsym, b0, bcount);
     } else {
-#define LAUNCH_GRP(L) hipLaunchKernelGGL(k_sync_frame_grp<L>, dim3(cdiv(ctx->C, GrpCfg<L>::CPW)), dim3(256), 0, st, \
-                           disc, offs, ctx->d_state, ctx->C, nblk, mode, ext_lock,                                  \
-                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0,                        \
-                           d_counts ? d_counts : ctx->d_counts, d_syms, d_nsyms, ctx->d_fsym, b0, bcount)
+#define LAUNCH_GRP(L) hipLaunchKernelGGL(k_sync_frame_grp<L>, dim3(cdiv(cn, GrpCfg<L>::CPW)), dim3(256), 0, st, \
+                           disc, offs, state, cn, nblk, mode, ext_lock, recs, recs ? rec_cap : 0,                \
+                           counts, syms, nsyms, fsym, b0, bcount)
         if (lpc == 64) LAUNCH_GRP(64); else if (lpc == 32) LAUNCH_GRP(32); else LAUNCH_GRP(16);
 #undef LAUNCH_GRP
     }
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+// demap / gather / Viterbi / Golay of the frames the framer queued, then the per-channel in-order bookkeeping,
+// for the channel range [c0, c0 + cn): its own work lists and counters (slot numbers are relative to the range)
+int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, hipStream_t st,
+                  int c0, int cn, int chunk, hipEvent_t ev_mid)
+{
+    m17gpu_rec_dev *recs = reinterpret_cast<m17gpu_rec_dev *>(d_recs) + (size_t)c0 * rec_cap;
+    int32_t *cnt = (d_counts ? d_counts : ctx->d_counts) + c0;
+    float *fsym = ctx->d_fsym + (size_t)c0 * rec_cap * kFrameSyms;
+    int32_t *work = ctx->d_work + 3 * (size_t)c0 * ctx->rec_cap_max;
+    int32_t *nwork = ctx->d_nwork + 4 * chunk;
+    const long long slots = (long long)cn * rec_cap;
+    hipLaunchKernelGGL(k_worklist, dim3(cdiv(slots, 1024)), dim3(1024), 0, st, recs, rec_cap, cnt, cn,
+                       work, nwork, (int)slots);
+    int grid = cdiv(slots, DQ_FRAMES) + 3;
+    if (grid > 256 * 6) grid = 256 * 6;                      // 6 single-wave workgroups per CU by LDS
+    hipLaunchKernelGGL(k_decode_quad, dim3(grid), dim3(64), 0, st, fsym, work, nwork,
+                       (int)slots, (const uint8_t *)nullptr, 0, recs, ctx->d_genc, ctx->d_gerr);
+    HIPCHK(hipGetLastError());
+    if (ev_mid) HIPCHK(hipEventRecord(ev_mid, st));
+    hipLaunchKernelGGL(k_book_chan, dim3(cn), dim3(64), 0, st, ctx->d_state + c0, recs, rec_cap, cnt, ctx->d_crc_basis);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -265,11 +303,12 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
         return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: mode 1 needs d_recs and 2*nblk+2 <= rec_cap <= 2*max_blocks+2");
     hipStream_t st = S(stream);
     int rc;
-    if ((mode & 0xFF) == 1) HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t) * 4, st));
+    const bool full = (mode & 0xFF) == 1;
+    if (full) HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t) * 4, st));
     hipEvent_t *ev = nullptr;
     if (ctx->profiling && ctx->ev_mode.size() < 512) {
         const size_t base = ctx->ev_pool.size();
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < 7; ++i) {
             hipEvent_t e;
             HIPCHK(hipEventCreate(&e));
             ctx->ev_pool.push_back(e);
@@ -277,48 +316,39 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
         ctx->ev_mode.push_back(mode & 0xFF);
         ev = &ctx->ev_pool[base];
     }
+    if (ev) HIPCHK(hipEventRecord(ev[5], st));
+    // (Channel chunks pipelined over internal streams -- chunk c+1's front end beside chunk c's timing stage beside
+    //  chunk c-1's decoder, 2..8 chunks at 16,384 channels -- were measured and dropped: 1.10 -> 1.10..1.24 ms per
+    //  step.  Every stage is issue-bound on the same vector units (scripts/micro/valu_rates.hip), so launches that
+    //  run side by side only share them.  The launch helpers still accept a channel range.)
+    {
 #define MARK(i) do { if (ev) HIPCHK(hipEventRecord(ev[i], st)); } while (0)
-    MARK(0);
-    // (Overlapping chunked front-end launches with the timing kernel on a second stream was
-    //  measured and dropped: 477 us vs 390 us per step at 1,024 x 50 -- the small launches lose
-    //  more occupancy than the overlap hides.  Both kernels still accept a block range.)
-    if (ctx->afc) {
-        // AFC closes a per-block loop through front end, timing loop and framer (k_frontend_afc): block by block
-        for (int b = 0; b < nblk; ++b) {
-            hipLaunchKernelGGL(k_frontend_afc, dim3(ctx->C), dim3(64), 0, st, reinterpret_cast<const uint32_t *>(d_iq),
-                               ctx->d_state, ctx->d_disc, ctx->d_offs, nblk, b);
-            HIPCHK(hipGetLastError());
+        MARK(0);
+        if (ctx->afc) {
+            // AFC closes a per-block loop through front end, timing loop and framer (k_frontend_afc): block by block
+            for (int b = 0; b < nblk; ++b) {
+                hipLaunchKernelGGL(k_frontend_afc, dim3(ctx->C), dim3(64), 0, st, reinterpret_cast<const uint32_t *>(d_iq),
+                                   ctx->d_state, ctx->d_disc, ctx->d_offs, nblk, b);
+                HIPCHK(hipGetLastError());
+                if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
+                                            d_syms, d_nsyms, st, -1, b, 1)) != M17GPU_OK) return rc;
+            }
+            MARK(1);
+            MARK(2);
+        } else {
+            if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, st)) != M17GPU_OK) return rc;
+            MARK(1);
             if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
-                                        d_syms, d_nsyms, st, -1, b, 1)) != M17GPU_OK) return rc;
+                                        d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
+            MARK(2);
         }
-        MARK(1);
-        MARK(2);
-    } else {
-        if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, st)) != M17GPU_OK) return rc;
-        MARK(1);
-        if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
-                                    d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
-        MARK(2);
-    }
-    if ((mode & 0xFF) == 1) {
-        int32_t *cnt = d_counts ? d_counts : ctx->d_counts;
-        const long long slots = (long long)ctx->C * rec_cap;
-        hipLaunchKernelGGL(k_worklist, dim3(cdiv(slots, 1024)), dim3(1024), 0, st,
-                           reinterpret_cast<const m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->C,
-                           ctx->d_work, ctx->d_nwork, (int)slots);
-        int grid = cdiv(slots, DQ_FRAMES) + 3;
-        if (grid > 256 * 6) grid = 256 * 6;                      // 6 single-wave workgroups per CU by LDS
-        hipLaunchKernelGGL(k_decode_quad, dim3(grid), dim3(64), 0, st, ctx->d_fsym, ctx->d_work, ctx->d_nwork,
-                           (int)slots, (const uint8_t *)nullptr, 0, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
-                           ctx->d_genc, ctx->d_gerr);
-        HIPCHK(hipGetLastError());
-        MARK(3);
-        hipLaunchKernelGGL(k_book_chan, dim3(ctx->C), dim3(64), 0, st, ctx->d_state,
-                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), rec_cap, cnt, ctx->d_crc_basis);
-        HIPCHK(hipGetLastError());
-        MARK(4);
-    }
+        if (full) {
+            if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, st, 0, ctx->C, 0, ev ? ev[3] : nullptr)) != M17GPU_OK) return rc;
+            MARK(4);
+        }
 #undef MARK
+    }
+    if (ev) HIPCHK(hipEventRecord(ev[6], st));
     return M17GPU_OK;
 }
 
@@ -387,22 +417,34 @@ int m17gpu_set_profiling(m17gpu_ctx *ctx, int on)
 
 int m17gpu_get_kernel_ms(m17gpu_ctx *ctx, float h_ms[4], int *h_calls)
 {
+    return m17gpu_get_call_ms(ctx, h_ms, nullptr, h_calls);
+}
+
+// As m17gpu_get_kernel_ms, plus the average duration of a whole m17gpu_rx_blocks call between two events on the
+// caller's stream (h_call_ms).  With channel chunks pipelined over internal streams the stage figures are those of
+// chunk 0 on its stream, beside the other chunks' kernels; the call duration is the number that counts.
+int m17gpu_get_call_ms(m17gpu_ctx *ctx, float h_ms[4], float *h_call_ms, int *h_calls)
+{
     if (!ctx || !h_ms) return fail(M17GPU_ERR_ARG, "m17gpu_get_kernel_ms: bad argument");
     ON_CTX_DEVICE(ctx);
-    double acc[4] = {0, 0, 0, 0};
+    double acc[4] = {0, 0, 0, 0}, call = 0;
     int n[4] = {0, 0, 0, 0};
     const size_t calls = ctx->ev_mode.size();
     for (size_t k = 0; k < calls; ++k) {
-        hipEvent_t *ev = &ctx->ev_pool[5 * k];
+        hipEvent_t *ev = &ctx->ev_pool[7 * k];
         const int last = ctx->ev_mode[k] == 1 ? 4 : 2;
-        HIPCHK(hipEventSynchronize(ev[last]));
+        HIPCHK(hipEventSynchronize(ev[6]));
         for (int i = 0; i < last; ++i) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
             acc[i] += ms; n[i]++;
         }
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ev[5], ev[6]));
+        call += ms;
     }
     for (int i = 0; i < 4; ++i) h_ms[i] = n[i] ? (float)(acc[i] / n[i]) : 0.0f;
+    if (h_call_ms) *h_call_ms = calls ? (float)(call / calls) : 0.0f;
     if (h_calls) *h_calls = (int)calls;
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     ctx->ev_pool.clear();
