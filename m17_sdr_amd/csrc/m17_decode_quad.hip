@@ -30,13 +30,12 @@ constexpr int DQ_CHUNK  = 32;                  // trellis steps per soft-bit chu
 constexpr int DQ_RING   = 2 * DQ_CHUNK;
 constexpr int DQ_DECW   = 31;                  // ceil(244 / 8) decision words per lane
 
-struct alignas(16) QuadFrame {                 // 1,552 B = 4 x 97 dwords: the 16 frames of a wave tile all 64 banks
-    float    sym[kFrameSyms];                  // frame symbols
+struct alignas(16) QuadFrame {                 // 784 B = 4 x 49 dwords: the 16 frames of a wave tile all 64 banks
     uint32_t dec[DQ_DECW][4];                  // decision nibbles: byte [t/2][quad lane], two steps per byte (122 x 4 used)
     float    ring[DQ_RING];                    // soft bits of the current chunk, (m1, m2) pairs
     uint8_t  bytes[32];                        // record payload
 };
-static_assert(sizeof(QuadFrame) == 1552, "QuadFrame layout");
+static_assert(sizeof(QuadFrame) == 784, "QuadFrame layout");
 
 template <int CTRL> __device__ __forceinline__ float dppf(float v)
 {
@@ -49,13 +48,18 @@ template <int CTRL> __device__ __forceinline__ int dppi(int v)
 
 // one soft bit of the de-punctured stream from its gather code (-1 = erasure):
 // m17_dsp_demap_symbol (m17_dsp.cpp:35-42) + m17_de_correlate_1 sign
-__device__ __forceinline__ float soft_from_code(int g, const float *sym, float cor)
+__device__ __forceinline__ int sym_of_code(int g) { return 8 + (((g < 0) ? 0 : (g & 0x3FF)) >> 1); }
+__device__ __forceinline__ float soft_from_raw(int g, float symval, float cor)
 {
     const int s = (g < 0) ? 0 : (g & 0x3FF);
-    const float m = sym[8 + (s >> 1)] * cor;
+    const float m = symval * cor;
     float v = (s & 1) ? (float)((double)fabsf(m) - 0.6666) : -m;
     if (g & 0x4000) v = -v;
     return (g < 0) ? 0.0f : v;                  // m17_puncture.cpp:54
+}
+__device__ __forceinline__ float soft_from_code(int g, const float *sym, float cor)
+{
+    return soft_from_raw(g, sym[sym_of_code(g)], cor);
 }
 
 // 1,024 threads per workgroup and one atomic per (workgroup, type): all waves appending to
@@ -97,7 +101,10 @@ void k_worklist(const m17gpu_rec_dev *__restrict__ recs, int rec_cap, const int3
 // One frame type per pass: `type` is wave-uniform (readfirstlane), so trellis length, table row
 // and every loop bound live in SGPRs.  Quads whose frame has another type (plain-batch mode
 // only; the work lists are per type) ride along on their own symbols and write nothing.
-__device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const int16_t *gt, const int16_t *lich, int type, int j, bool writeback, uint32_t r0_keep,
+// The frame's 192 symbols stay in global memory (gs; written by the framer just before, so L2-resident): every soft
+// bit is one gather through the table, the gathers of the NEXT 32 trellis steps fly while the current 32 are
+// processed.  Keeping the symbols out of LDS halves the kernel's LDS per wave and doubles the waves per CU.
+__device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__restrict__ gs, const int16_t *gt, const int16_t *lich, int type, int j, bool writeback, uint32_t r0_keep,
                                                  m17gpu_rec_dev *rec, const uint32_t (&sgn)[4], const bool (&selA)[4],
                                                  const uint16_t *genc, const uint16_t *gerr,
                                                  unsigned long long *acc_, unsigned long long &last_)
@@ -110,7 +117,7 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const int16_t *gt
     {
         float sum = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sum += fabsf(F.sym[i]);
+        for (int i = 0; i < 8; ++i) sum += fabsf(gs[i]);
         cor = 8.0f / sum;                      // (float)(8.0/(double)sum), see limit()
     }
     reinterpret_cast<uint2 *>(F.bytes)[j] = make_uint2(0u, 0u);
@@ -119,7 +126,7 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const int16_t *gt
     if (type == 2) {
         uint32_t word = 0;
         for (int k = 0; k < 24; ++k) {
-            const float v = soft_from_code((int)lich[j * 24 + k], F.sym, cor);
+            const float v = soft_from_code((int)lich[j * 24 + k], gs, cor);
             word = (word << 1) | (v >= 0.0f ? 1u : 0u);                 // hard_decode_24_bits
         }
         int e;
@@ -140,14 +147,21 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const int16_t *gt
 #pragma unroll
     for (int i = 0; i < 4; ++i) acm[i] = (j == 0 && i == 0) ? 1.0f : 0.0f;     // :150-153
     uint32_t dw = 0;
+    // soft bits of steps c0 .. c0+31: quad lane j makes ring[j], ring[j+4], ...  (row padded with erasures)
+    float raw[2 * DQ_CHUNK / 4];
+    auto fetch_chunk = [&](int c0) {
+#pragma unroll
+        for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) raw[r] = gs[sym_of_code((int)gt[(2 * c0 + j + 4 * r) & 511])];
+    };
+    auto commit_chunk = [&](int c0) {
+#pragma unroll
+        for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) F.ring[j + 4 * r] = soft_from_raw((int)gt[(2 * c0 + j + 4 * r) & 511], raw[r], cor);
+    };
+    fetch_chunk(0);
+    commit_chunk(0);
+    group_sync();
     for (int c0 = 0; c0 < steps; c0 += DQ_CHUNK) {
-        // soft bits of steps c0 .. c0+31: quad lane j makes ring[j], ring[j+4], ...
-#pragma unroll 4
-        for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) {
-            const int k = 2 * c0 + j + 4 * r;
-            F.ring[j + 4 * r] = soft_from_code((int)gt[k & 511], F.sym, cor);     // row padded with erasures
-        }
-        group_sync();
+        if (c0 + DQ_CHUNK < steps) fetch_chunk(c0 + DQ_CHUNK);       // in flight during this chunk's butterflies
         STAMP(2);
         const int tend2 = min(DQ_CHUNK, steps - c0) >> 1;     // steps is even
         const float4 *ring4 = reinterpret_cast<const float4 *>(F.ring);
@@ -182,6 +196,7 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const int16_t *gt
             cur = nxt;
         }
         group_sync();
+        if (c0 + DQ_CHUNK < steps) { commit_chunk(c0 + DQ_CHUNK); group_sync(); }
         STAMP(3);
     }
 
@@ -242,7 +257,7 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
                    m17gpu_rec_dev *__restrict__ recs,
                    const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr)
 {
-    __shared__ __attribute__((aligned(16))) QuadFrame fr[DQ_FRAMES];        // 24.8 KB (+1.2 KB tables): six waves per CU
+    __shared__ __attribute__((aligned(16))) QuadFrame fr[DQ_FRAMES];        // 12.3 KB (+1.2 KB tables): eleven waves per CU
     __shared__ int16_t gt_row[512];                                         // DevTables.gather row of the current type
     __shared__ int16_t lich_row[96];
     const int lane = lane_id(), q = lane >> 2, j = lane & 3;
@@ -288,13 +303,7 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
             slot = active ? item : n_plain - 1;
             qtype = (int)types[slot];
         }
-        // ---- symbols in
-        {
-            const float4 *src = reinterpret_cast<const float4 *>(fsym + (size_t)slot * kFrameSyms);
-            float4 *dst = reinterpret_cast<float4 *>(F.sym);
-#pragma unroll
-            for (int r = 0; r < 12; ++r) dst[j + 4 * r] = src[j + 4 * r];
-        }
+        const float *gs = fsym + (size_t)slot * kFrameSyms;          // the frame's symbols, read in place
         m17gpu_rec_dev *rec = &recs[slot];
         const uint32_t r0_keep = work ? reinterpret_cast<const uint32_t *>(rec)[0] : (uint32_t)qtype;
         group_sync();
@@ -308,7 +317,7 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
                 row_type = type;
                 group_sync();
             }
-            decode_quad_pass(F, gt_row, lich_row, type, j, active && qtype == type, r0_keep, rec, sgn, selA, genc, gerr, acc_, last_);
+            decode_quad_pass(F, gs, gt_row, lich_row, type, j, active && qtype == type, r0_keep, rec, sgn, selA, genc, gerr, acc_, last_);
         }
         STAMP(5);
     }

@@ -206,7 +206,7 @@ int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_c
     hipLaunchKernelGGL(k_worklist, dim3(cdiv(slots, 1024)), dim3(1024), 0, st, recs, rec_cap, cnt, cn,
                        work, nwork, (int)slots);
     int grid = cdiv(slots, DQ_FRAMES) + 3;
-    if (grid > 256 * 6) grid = 256 * 6;                      // 6 single-wave workgroups per CU by LDS
+    if (grid > 256 * 11) grid = 256 * 11;                    // 11 single-wave workgroups per CU by LDS
     hipLaunchKernelGGL(k_decode_quad, dim3(grid), dim3(64), 0, st, fsym, work, nwork,
                        (int)slots, (const uint8_t *)nullptr, 0, recs, ctx->d_genc, ctx->d_gerr);
     HIPCHK(hipGetLastError());
@@ -597,7 +597,7 @@ int m17gpu_decode_frames(m17gpu_ctx *ctx, const float *d_sym, const uint8_t *d_t
     hipStream_t st = S(stream);
     HIPCHK(hipMemsetAsync(d_recs, 0, sizeof(m17gpu_rec) * (size_t)n, st));
     int grid = cdiv(n, DQ_FRAMES);
-    if (grid > 256 * 6) grid = 256 * 6;
+    if (grid > 256 * 11) grid = 256 * 11;
     hipLaunchKernelGGL(k_decode_quad, dim3(grid), dim3(64), 0, st, d_sym, (const int32_t *)nullptr,
                        (const int32_t *)nullptr, 0, d_type, n, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
                        ctx->d_genc, ctx->d_gerr);
