@@ -105,7 +105,7 @@ void k_worklist(const m17gpu_rec_dev *__restrict__ recs, int rec_cap, const int3
 // bit is one gather through the table, the gathers of the NEXT 32 trellis steps fly while the current 32 are
 // processed.  Keeping the symbols out of LDS halves the kernel's LDS per wave and doubles the waves per CU.
 __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__restrict__ gs, const int16_t *gt, const int16_t *lich, int type, int j, bool writeback, uint32_t r0_keep,
-                                                 m17gpu_rec_dev *rec, const uint32_t (&sgn)[4], const bool (&selA)[4],
+                                                 m17gpu_rec_dev *rec, const v2f (&C1)[2], const v2f (&C2)[2],
                                                  const uint16_t *genc, const uint16_t *gerr,
                                                  unsigned long long *acc_, unsigned long long &last_)
 {
@@ -143,10 +143,30 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__re
     STAMP(1);
 
     // ---- forward pass (m17_viterbi_decode, m17_conv.cpp:148-158)
-    float acm[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acm[i] = (j == 0 && i == 0) ? 1.0f : 0.0f;     // :150-153
+    // path metrics of states 4j .. 4j+3: two register sets, a trellis step reads one and writes the other
+    float A0 = (j == 0) ? 1.0f : 0.0f, A1 = 0.0f, A2 = 0.0f, A3 = 0.0f, B0, B1, B2, B3;     // :150-153
     uint32_t dw = 0;
+    // One add-compare-select (BF, m17_conv.cpp:19): ta = acm[even predecessor] + M, tb = acm[odd predecessor] - M with
+    // the predecessors' metrics arriving as DPP operands of the adds (old states 2v, 2v+1 mod 16 sit in quad lane
+    // (2j) mod 4 for v = 4j, 4j+1 and (2j+1) mod 4 above); strict '>' keeps the even one, ties and NaN the odd one;
+    // the decision enters the nibble through the carry of dw + dw.  Written out so that every step is exactly these
+    // five instructions per state (the compiler's own choice was ~9, with packed adds fed by eight v_mov_dpp).
+    // DPP reads need their source two instructions old: every source here was written at least five earlier.
+#define DQ_ACS(nw, pa, pb, PERM, M) do { float tb_;                                                      \
+        asm volatile("v_add_f32_dpp %0, %3, %5 quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"       \
+                     "v_sub_f32_dpp %1, %4, %5 quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"       \
+                     "v_cmp_ngt_f32 vcc, %0, %1\n\t"                                                    \
+                     "v_cndmask_b32 %0, %0, %1, vcc\n\t"                                                \
+                     "v_addc_co_u32 %2, vcc, %2, %2, vcc"                                                \
+                     : "=&v"(nw), "=&v"(tb_), "+v"(dw) : "v"(pa), "v"(pb), "v"(M) : "vcc"); } while (0)
+#define DQ_STEP(m1, m2, a0, a1, a2, a3, n0, n1, n2, n3) do {                                              \
+        const v2f mm1 = {m1, m1}, mm2 = {m2, m2};                                                       \
+        const v2f Ma = __builtin_elementwise_fma(C2[0], mm2, C1[0] * mm1);       /* states 4j, 4j+1 */   \
+        const v2f Mb = __builtin_elementwise_fma(C2[1], mm2, C1[1] * mm1);       /* states 4j+2, 4j+3 */ \
+        DQ_ACS(n3, a2, a3, "[1,3,1,3]", Mb.y);        /* descending: nibble bit i = decision of state 4j+i */ \
+        DQ_ACS(n2, a0, a1, "[1,3,1,3]", Mb.x);                                                          \
+        DQ_ACS(n1, a2, a3, "[0,2,0,2]", Ma.y);                                                          \
+        DQ_ACS(n0, a0, a1, "[0,2,0,2]", Ma.x); } while (0)
     // soft bits of steps c0 .. c0+31: quad lane j makes ring[j], ring[j+4], ...  (row padded with erasures)
     float raw[2 * DQ_CHUNK / 4];
     auto fetch_chunk = [&](int c0) {
@@ -160,6 +180,7 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__re
     fetch_chunk(0);
     commit_chunk(0);
     group_sync();
+    asm volatile("s_nop 1");
     for (int c0 = 0; c0 < steps; c0 += DQ_CHUNK) {
         if (c0 + DQ_CHUNK < steps) fetch_chunk(c0 + DQ_CHUNK);       // in flight during this chunk's butterflies
         STAMP(2);
@@ -168,29 +189,8 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__re
         float4 cur = ring4[0];
         for (int t2 = 0; t2 < tend2; ++t2) {
             const float4 nxt = ring4[min(t2 + 1, DQ_CHUNK / 2 - 1)];            // one pair ahead: no LDS wait per step
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float m1 = h ? cur.z : cur.x, m2 = h ? cur.w : cur.y;
-                const float a = m1 + m2;                     // metric[3]
-                const float b = m1 + (-m2);                  // metric[2]
-                float nw[4];
-#pragma unroll
-                for (int i = 3; i >= 0; --i) {               // descending: nibble bit i = decision of state 4j+i
-                    const float M = __uint_as_float(__float_as_uint(selA[i] ? a : b) ^ sgn[i]);
-                    // old states 2v, 2v+1 (mod 16): quad lane (2j) mod 4 for i < 2, (2j+1) mod 4 above
-                    float pe, po;
-                    if (i == 0)      { pe = dppf<0x88>(acm[0]); po = dppf<0x88>(acm[1]); }
-                    else if (i == 1) { pe = dppf<0x88>(acm[2]); po = dppf<0x88>(acm[3]); }
-                    else if (i == 2) { pe = dppf<0xDD>(acm[0]); po = dppf<0xDD>(acm[1]); }
-                    else             { pe = dppf<0xDD>(acm[2]); po = dppf<0xDD>(acm[3]); }
-                    const float ta = pe + M, tb = po - M;
-                    const bool odd = !(ta > tb);             // strict '>' : ties pick the odd predecessor
-                    nw[i] = odd ? tb : ta;
-                    dw = (dw << 1) | (odd ? 1u : 0u);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acm[i] = nw[i];
-            }
+            DQ_STEP(cur.x, cur.y, A0, A1, A2, A3, B0, B1, B2, B3);
+            DQ_STEP(cur.z, cur.w, B0, B1, B2, B3, A0, A1, A2, A3);
             // two steps per byte: even step in the high nibble
             reinterpret_cast<uint8_t *>(F.dec)[4 * ((c0 >> 1) + t2) + j] = (uint8_t)dw;
             cur = nxt;
@@ -264,12 +264,14 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
     QuadFrame &F = fr[q];
 
     // per-lane constants of the butterfly: state v = 4j+i, even predecessor's metric index
-    uint32_t sgn[4]; bool selA[4];
+    // metric[idx] = (idx & 2 ? m1 : -m1) + (idx & 1 ? m2 : -m2)  (m17_conv.cpp:88-91) = c1 * m1 + c2 * m2 with c = +-1:
+    // states (4j, 4j+1) in C[0], (4j+2, 4j+3) in C[1]
+    v2f C1[2], C2[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = c_tab.bm_even[4 * j + i];
-        selA[i] = (idx == 0 || idx == 3);         // +-(m1 + m2), else +-(m1 - m2)
-        sgn[i] = (idx < 2) ? 0x80000000u : 0u;
+        const float c1 = (idx & 2) ? 1.0f : -1.0f, c2 = (idx & 1) ? 1.0f : -1.0f;
+        if (i & 1) { C1[i >> 1].y = c1; C2[i >> 1].y = c2; } else { C1[i >> 1].x = c1; C2[i >> 1].x = c2; }
     }
 
     for (int i = lane; i < 96; i += 64) lich_row[i] = c_tab.lich[i];
@@ -317,7 +319,7 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
                 row_type = type;
                 group_sync();
             }
-            decode_quad_pass(F, gs, gt_row, lich_row, type, j, active && qtype == type, r0_keep, rec, sgn, selA, genc, gerr, acc_, last_);
+            decode_quad_pass(F, gs, gt_row, lich_row, type, j, active && qtype == type, r0_keep, rec, C1, C2, genc, gerr, acc_, last_);
         }
         STAMP(5);
     }
