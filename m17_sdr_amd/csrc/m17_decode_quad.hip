@@ -46,20 +46,46 @@ template <int CTRL> __device__ __forceinline__ int dppi(int v)
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
-// one soft bit of the de-punctured stream from its gather code (-1 = erasure):
-// m17_dsp_demap_symbol (m17_dsp.cpp:35-42) + m17_de_correlate_1 sign
-__device__ __forceinline__ int sym_of_code(int g) { return 8 + (((g < 0) ? 0 : (g & 0x3FF)) >> 1); }
-__device__ __forceinline__ float soft_from_raw(int g, float symval, float cor)
+// The gather tables (DevTables.gather / .lich: source soft-bit index, 0x4000 = negated, -1 = erasure) are re-coded
+// once per workgroup into LDS entries the inner loops can use without decoding:
+//   bits 0..9   byte offset of the source symbol in the frame (4 * (8 + s / 2))
+//   bit  10     the soft bit is the dibit's second one (|m| - 0.6666), else the first (-m)   m17_dsp.cpp:35-42
+//   bit  12     valid (0 = erasure, m17_puncture.cpp:54)
+//   bit  31     negate (m17_de_correlate_1)
+__host__ __device__ inline uint32_t dq_entry(int g)
 {
-    const int s = (g < 0) ? 0 : (g & 0x3FF);
-    const float m = symval * cor;
-    float v = (s & 1) ? (float)((double)fabsf(m) - 0.6666) : -m;
-    if (g & 0x4000) v = -v;
-    return (g < 0) ? 0.0f : v;                  // m17_puncture.cpp:54
+    if (g < 0) return 32u;
+    const uint32_t s = (uint32_t)g & 0x3FFu;
+    return (4u * (8u + (s >> 1))) | ((s & 1u) << 10) | (1u << 12) | (((uint32_t)g & 0x4000u) ? 0x80000000u : 0u);
 }
-__device__ __forceinline__ float soft_from_code(int g, const float *sym, float cor)
+__device__ __forceinline__ float dq_symbol(const float *gs, uint32_t e)
 {
-    return soft_from_raw(g, sym[sym_of_code(g)], cor);
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(gs) + (e & 0x3FFu));
+}
+// ncor = -cor: symval * ncor == -(symval * cor) bit for bit, and |.| of the two is the same
+__device__ __forceinline__ float dq_soft(uint32_t e, float symval, float ncor)
+{
+    const float nm = symval * ncor;
+    const float odd = (float)((double)fabsf(nm) - 0.6666);
+    const uint32_t pm = (uint32_t)__builtin_amdgcn_sbfe((int)e, 10, 1);              // all ones: second bit of the dibit
+    uint32_t v = (pm & __float_as_uint(odd)) | (~pm & __float_as_uint(nm));
+    v ^= e & 0x80000000u;
+    v &= (uint32_t)__builtin_amdgcn_sbfe((int)e, 12, 1);                             // erasure: +0.0
+    return __uint_as_float(v);
+}
+// LICH entries: the hard decision `soft >= 0` (hard_decode_24_bits, m17_golay.cpp) as one compare y >= T:
+//   first bit:   -m >= 0 (negated: m >= 0)                        y = -m (m),      T = 0
+//   second bit:  (float)((double)|m| - 0.6666) >= 0  <=>  |m| >= RU(0.6666) in fp32 (the difference is an exact
+//                non-zero double of magnitude > 1e-9, so the conversion keeps its sign); negated: |m| <= RD(0.6666)
+//                                                                  y = |m| (-|m|),  T = RU (-RD)
+__host__ __device__ inline DqLich dq_lich_entry(int g)       // e: offset, bit 10 and bit 31 as above
+{
+    // 0.6666 lies strictly between the floats 0x3F2AA64C (0.66659999) and 0x3F2AA64D (0.66660005)
+    DqLich L;
+    L.e = dq_entry(g);
+    const bool second = (L.e >> 10) & 1u, neg = (L.e >> 31) != 0u;
+    L.T = !second ? 0.0f : (neg ? -__builtin_bit_cast(float, 0x3F2AA64Cu) : __builtin_bit_cast(float, 0x3F2AA64Du));
+    return L;
 }
 
 // 1,024 threads per workgroup and one atomic per (workgroup, type): all waves appending to
@@ -104,7 +130,7 @@ void k_worklist(const m17gpu_rec_dev *__restrict__ recs, int rec_cap, const int3
 // The frame's 192 symbols stay in global memory (gs; written by the framer just before, so L2-resident): every soft
 // bit is one gather through the table, the gathers of the NEXT 32 trellis steps fly while the current 32 are
 // processed.  Keeping the symbols out of LDS halves the kernel's LDS per wave and doubles the waves per CU.
-__device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__restrict__ gs, const int16_t *gt, const int16_t *lich, int type, int j, bool writeback, uint32_t r0_keep,
+__device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__restrict__ gs, const uint32_t *gt, const DqLich *lich, int type, int j, bool writeback, uint32_t r0_keep,
                                                  m17gpu_rec_dev *rec, const v2f (&C1)[2], const v2f (&C2)[2],
                                                  const uint16_t *genc, const uint16_t *gerr,
                                                  unsigned long long *acc_, unsigned long long &last_)
@@ -113,21 +139,25 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__re
     const int nbits = (type == 1) ? 240 : (type == 2 ? 144 : 208);
     const int boff = (type == 2) ? 6 : 0;
     // m17_dsp_demap_frame (m17_dsp.cpp:82-95): amplitude reference from the 8 sync symbols
-    float cor;
+    float ncor;
     {
         float sum = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) sum += fabsf(gs[i]);
-        cor = 8.0f / sum;                      // (float)(8.0/(double)sum), see limit()
+        ncor = -(8.0f / sum);                  // cor = (float)(8.0/(double)sum), see limit()
     }
     reinterpret_cast<uint2 *>(F.bytes)[j] = make_uint2(0u, 0u);
     // ---- LICH (m17_rx_parse.cpp:118-135): quad lane j decodes Golay word j
     uint32_t gerrs = 0;
     if (type == 2) {
         uint32_t word = 0;
-        for (int k = 0; k < 24; ++k) {
-            const float v = soft_from_code((int)lich[j * 24 + k], gs, cor);
-            word = (word << 1) | (v >= 0.0f ? 1u : 0u);                 // hard_decode_24_bits
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {                                   // hard_decode_24_bits: soft >= 0, as y >= T
+            const DqLich L = lich[j * 24 + k];
+            const float nm = dq_symbol(gs, L.e) * ncor;
+            const uint32_t am = (L.e << 21) & 0x80000000u;               // second bit of the dibit: |.|
+            const float y = __uint_as_float((__float_as_uint(nm) & ~am) ^ (L.e & 0x80000000u));
+            word = (word << 1) | (y >= L.T ? 1u : 0u);
         }
         int e;
         const int w = golay_decode(word, genc, gerr, e);
@@ -169,16 +199,17 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__re
         DQ_ACS(n0, a0, a1, "[0,2,0,2]", Ma.x); } while (0)
     // soft bits of steps c0 .. c0+31: quad lane j makes ring[j], ring[j+4], ...  (row padded with erasures)
     float raw[2 * DQ_CHUNK / 4];
+    uint32_t ent[2 * DQ_CHUNK / 4];
     auto fetch_chunk = [&](int c0) {
 #pragma unroll
-        for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) raw[r] = gs[sym_of_code((int)gt[(2 * c0 + j + 4 * r) & 511])];
+        for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) { ent[r] = gt[(2 * c0 + j + 4 * r) & 511]; raw[r] = dq_symbol(gs, ent[r]); }
     };
-    auto commit_chunk = [&](int c0) {
+    auto commit_chunk = [&]() {
 #pragma unroll
-        for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) F.ring[j + 4 * r] = soft_from_raw((int)gt[(2 * c0 + j + 4 * r) & 511], raw[r], cor);
+        for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) F.ring[j + 4 * r] = dq_soft(ent[r], raw[r], ncor);
     };
     fetch_chunk(0);
-    commit_chunk(0);
+    commit_chunk();
     group_sync();
     asm volatile("s_nop 1");
     for (int c0 = 0; c0 < steps; c0 += DQ_CHUNK) {
@@ -196,37 +227,34 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__re
             cur = nxt;
         }
         group_sync();
-        if (c0 + DQ_CHUNK < steps) { commit_chunk(c0 + DQ_CHUNK); group_sync(); }
+        if (c0 + DQ_CHUNK < steps) { commit_chunk(); group_sync(); }
         STAMP(3);
     }
 
     // ---- traceback from state 0 (:160-166) and pack_1_to_8(&bits[1], ...) in one go.
     // dword t/2 of dec holds the four lanes' bytes: decision of state s at step t is bit
-    // 8 (s >> 2) + (s & 3) + (t even ? 4 : 0).
+    // 8 (s >> 2) + (s & 3) + (t even ? 4 : 0).  The walk keeps its decisions in a shift register: the state after
+    // step t is its low nibble (d[t+3] d[t+2] d[t+1] d[t]), so bits[t] = state >> 3 = d[t+3] and output bit
+    // u = t - 1 is d[u+4]: after step t = 4 + 32 w the register IS output word w, bit k = output bit 32 w + k.
     {
-        int state = 0;
-        uint32_t acc = 0;
+        uint32_t hist = 0;
         const uint4 *dq = reinterpret_cast<const uint4 *>(F.dec);
         for (int g = (steps - 1) >> 3; g >= 0; --g) {
             const uint4 W = dq[g];                         // steps 8g .. 8g+7, one LDS read
 #pragma unroll
             for (int tt = 7; tt >= 0; --tt) {
-                const int t = 8 * g + tt;
-                if (t < steps) {                           // scalar: only the top group is partial
+                if (8 * g + tt < steps) {                  // scalar: only the top group is partial
                     const uint32_t wv = (tt >> 1) == 0 ? W.x : ((tt >> 1) == 1 ? W.y : ((tt >> 1) == 2 ? W.z : W.w));
-                    const int pos = (((state & 12) << 1) | (state & 3)) + ((tt & 1) ? 0 : 4);
-                    const int d = (int)((wv >> pos) & 1u);
-                    state = ((state << 1) & 15) | d;
-                    const int u = t - 1;                   // bits[t] -> output bit u
-                    if (u >= 0 && u < nbits) acc |= (uint32_t)(state >> 3) << ((u & 31) ^ 7);
+                    const uint32_t pos = (hist & 12u) + (hist & 15u) + ((tt & 1) ? 0u : 4u);
+                    hist = (hist << 1) | ((wv >> pos) & 1u);
                 }
-                // after u = 8g (tt == 1) output word g/4 is complete when 8g is a multiple of 32
-                if (tt == 1 && (g & 3) == 0 && 8 * g < nbits) {
+                if (tt == 4 && (g & 3) == 0 && 8 * g < nbits) {
+                    // pack_1_to_8: output bit u sits at bit 7 - (u & 7) of byte u / 8
+                    const uint32_t word = __builtin_bswap32(__builtin_bitreverse32(hist));
                     if (j == 0) {
                         uint16_t *o = reinterpret_cast<uint16_t *>(F.bytes + boff + 4 * (g >> 2));
-                        o[0] = (uint16_t)acc; o[1] = (uint16_t)(acc >> 16);
+                        o[0] = (uint16_t)word; o[1] = (uint16_t)(word >> 16);
                     }
-                    acc = 0;
                 }
             }
         }
@@ -257,9 +285,9 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
                    m17gpu_rec_dev *__restrict__ recs,
                    const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr)
 {
-    __shared__ __attribute__((aligned(16))) QuadFrame fr[DQ_FRAMES];        // 12.3 KB (+1.2 KB tables): eleven waves per CU
-    __shared__ int16_t gt_row[512];                                         // DevTables.gather row of the current type
-    __shared__ int16_t lich_row[96];
+    __shared__ __attribute__((aligned(16))) QuadFrame fr[DQ_FRAMES];        // 12.3 KB (+2 KB table): eleven waves per CU
+    __shared__ uint32_t gt_row[512];                                        // DevTables.gather row of the current type, re-coded
+    const DqLich *lich_row = c_tab.lich_q;                                  // lane-indexed: vector loads, cache-resident
     const int lane = lane_id(), q = lane >> 2, j = lane & 3;
     QuadFrame &F = fr[q];
 
@@ -274,7 +302,6 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
         if (i & 1) { C1[i >> 1].y = c1; C2[i >> 1].y = c2; } else { C1[i >> 1].x = c1; C2[i >> 1].x = c2; }
     }
 
-    for (int i = lane; i < 96; i += 64) lich_row[i] = c_tab.lich[i];
     int row_type = 0;
     int n1 = 0, n2 = 0, n3 = 0;
     if (work) { n1 = nwork[0]; n2 = nwork[1]; n3 = nwork[2]; }
@@ -315,7 +342,12 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
             const int type = (pass == 0) ? 2 : (pass == 1 ? 1 : 3);
             if (__ballot(qtype == type) == 0ull) continue;
             if (row_type != type) {
-                for (int i = lane; i < 512; i += 64) gt_row[i] = (i < 488) ? c_tab.gather[type][i] : (int16_t)-1;
+                for (int i = lane; i < 512; i += 64) {
+                    gt_row[i] = dq_entry((i < 488) ? (int)c_tab.gather[type][i] : -1);
+#ifdef DQ_ABL_COALESCED
+                    gt_row[i] = (gt_row[i] & ~0x3FFu) | (4u * (8u + (uint32_t)(i % 184)));
+#endif
+                }
                 row_type = type;
                 group_sync();
             }

@@ -77,6 +77,9 @@ struct ChanState {
 };
 static_assert(sizeof(ChanState) == 1920, "ChanState layout");
 
+// one LICH soft-bit source re-coded for the decoder (m17_decode_quad.hip: dq_lich_entry)
+struct DqLich { uint32_t e; float T; };
+
 // constant tables (built on the host by m17::tables())
 struct DevTables {
     float    mf[kPhases][32];        // matched filter taps, 31 used
@@ -84,6 +87,7 @@ struct DevTables {
     float    tap_pairs[kPhases][64]; // the same taps as (matched, derivative) pairs, 32 pairs per branch (pair 31 = 0)
     int16_t  gather[4][488];         // -1 erasure, else src | 0x4000 when negated
     int16_t  lich[96];
+    DqLich   lich_q[96];             // lich[] as the decoder reads it
     int16_t  glen[4];
     uint8_t  bm_even[16], bm_odd[16];
     uint16_t crc[256];

@@ -356,7 +356,15 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
             GCNT(10);
             if (flock) {
                 const int cnt = min(kFrameSyms - fclk, n - pos);
-                for (int q = gl; q < cnt; q += LPC) my.f[fclk + q] = my.h[8 + pos + q];
+                {
+                    // reads batched ahead of the writes: the strided loop paid one LDS round trip per element
+                    constexpr int R = kFrameSyms / LPC;
+                    float t[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) t[r] = (gl + LPC * r < cnt) ? my.h[8 + pos + gl + LPC * r] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) if (gl + LPC * r < cnt) my.f[fclk + gl + LPC * r] = t[r];
+                }
                 fclk += cnt; pos += cnt;
                 wave_fence();
                 if (fclk == kFrameSyms) {
@@ -379,7 +387,12 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
                     emit_record_grp(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
                     if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
                         float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kFrameSyms;
-                        for (int q = gl; q < kFrameSyms; q += LPC) fd[q] = my.f[q];
+                        constexpr int R = kFrameSyms / LPC;
+                        float t[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) t[r] = my.f[gl + LPC * r];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) fd[gl + LPC * r] = t[r];
                     }
                     nrec++;
                     if (unlock) {

@@ -95,7 +95,10 @@ int upload_tables(m17gpu_ctx *ctx)
         }
     }
     for (int j = 0; j < 96; ++j)
+    {
         h.lich[j] = (int16_t)(T.lich_src[j] | (T.lich_sign[j] < 0 ? 0x4000 : 0));
+        h.lich_q[j] = dq_lich_entry((int)h.lich[j]);
+    }
     std::memcpy(h.bm_even, T.bm_even, 16);
     std::memcpy(h.bm_odd, T.bm_odd, 16);
     std::memcpy(h.crc, T.crc, sizeof h.crc);
