@@ -28,14 +28,22 @@ namespace m17dev {
 constexpr int DQ_FRAMES = 16;                  // frames per wave
 constexpr int DQ_CHUNK  = 32;                  // trellis steps per soft-bit chunk
 constexpr int DQ_RING   = 2 * DQ_CHUNK;
-constexpr int DQ_DECW   = 31;                  // ceil(244 / 8) decision words per lane
+constexpr int DQ_DECW   = 31;                  // ceil(244 / 8) decision rows: any frame type
+constexpr int DQ_DECW_STREAM = 19;             // ceil(148 / 8): stream frames
 
-struct alignas(16) QuadFrame {                 // 784 B = 4 x 49 dwords: the 16 frames of a wave tile all 64 banks
-    uint32_t dec[DQ_DECW][4];                  // decision nibbles: byte [t/2][quad lane], two steps per byte (122 x 4 used)
-    float    ring[DQ_RING];                    // soft bits of the current chunk, (m1, m2) pairs
-    uint8_t  bytes[32];                        // record payload
+// Per-frame LDS.  The record payload bytes are assembled after the forward pass, in the ring's place.
+// DECW = 31: 752 B = 4 x 47 dwords, DECW = 19: 560 B = 4 x 35 dwords -- either way the 16 frames of a wave
+// start 4 banks apart modulo 64, so the same field of all frames tiles the banks.
+template <int DECW>
+struct alignas(16) QuadFrameT {
+    uint32_t dec[DECW][4];                     // decision nibbles: byte [t/2][quad lane], two steps per byte
+    union {
+        float   ring[DQ_RING];                 // soft bits of the current chunk, (m1, m2) pairs
+        uint8_t bytes[32];                     // record payload
+    };
+    static constexpr int kDecw = DECW;
 };
-static_assert(sizeof(QuadFrame) == 784, "QuadFrame layout");
+static_assert(sizeof(QuadFrameT<DQ_DECW>) == 752 && sizeof(QuadFrameT<DQ_DECW_STREAM>) == 560, "QuadFrame layout");
 
 template <int CTRL> __device__ __forceinline__ float dppf(float v)
 {
@@ -124,51 +132,99 @@ void k_worklist(const m17gpu_rec_dev *__restrict__ recs, int rec_cap, const int3
     if (ty) work[(size_t)(ty - 1) * cap + wbase[ty - 1][wave] + (int)__popcll(m[ty - 1] & below)] = (int32_t)i;
 }
 
-// One frame type per pass: `type` is wave-uniform (readfirstlane), so trellis length, table row
-// and every loop bound live in SGPRs.  Quads whose frame has another type (plain-batch mode
-// only; the work lists are per type) ride along on their own symbols and write nothing.
-// The frame's 192 symbols stay in global memory (gs; written by the framer just before, so L2-resident): every soft
-// bit is one gather through the table, the gathers of the NEXT 32 trellis steps fly while the current 32 are
-// processed.  Keeping the symbols out of LDS halves the kernel's LDS per wave and doubles the waves per CU.
-__device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__restrict__ gs, const uint32_t *gt, const DqLich *lich, int type, int j, bool writeback, uint32_t r0_keep,
+// One frame type per pass: `type` is wave-uniform (a template constant for the stream kernel), so trellis length,
+// table row and every loop bound live in SGPRs.  Quads whose frame has another type (plain-batch mode only; the work
+// lists are per type) ride along on their own symbols and write nothing.
+// The frame's 192 symbols stay in global memory (gs; written by the framer just before): every soft bit is one gather
+// through the table, the gathers of the NEXT 32 trellis steps fly while the current 32 are processed.  Everything a
+// frame needs first -- the 8 sync symbols, the LICH symbols, the first chunk -- is requested in one go at the top, and
+// the two dependent Golay table reads ride under the forward pass, so a frame pays one memory round trip, not five.
+// Fences inside are wave-local LDS fences: a workgroup-scope fence would also drain the loads in flight.
+template <int DECW, int TYPE_CT>
+__device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW> &F, const float *__restrict__ gs, const uint32_t *gt,
+                                                 const DqLich *lich, int type_rt, int j, bool writeback, uint32_t r0_keep,
                                                  m17gpu_rec_dev *rec, const v2f (&C1)[2], const v2f (&C2)[2],
                                                  const uint16_t *genc, const uint16_t *gerr,
                                                  unsigned long long *acc_, unsigned long long &last_)
 {
+    const int type = TYPE_CT ? TYPE_CT : type_rt;
     const int steps = (type == 1) ? 244 : (type == 2 ? 148 : 210);       // DevTables.glen / 2
     const int nbits = (type == 1) ? 240 : (type == 2 ? 144 : 208);
     const int boff = (type == 2) ? 6 : 0;
-    // m17_dsp_demap_frame (m17_dsp.cpp:82-95): amplitude reference from the 8 sync symbols
+    // soft bits of steps c0 .. c0+31 (row padded with erasures).  Plain 192-symbol frames (TYPE_CT == 0): quad lane j
+    // makes ring[j], ring[j+4], ..., each from a gather through the table.  Regrouped stream slots (TYPE_CT == 2,
+    // m17_dev.h kSlotFloats): lane j makes ring[16j .. 16j+15] from 64 contiguous bytes of the slot.
+    // (the table entry is read again at commit time: holding 16 of them across the butterflies costs registers the
+    //  16-waves-per-CU budget of 128 does not have)
+    constexpr bool REGROUPED = (TYPE_CT == 2);
+    float raw[2 * DQ_CHUNK / 4];
     float ncor;
+    auto fetch_chunk = [&](int c0) {
+        if constexpr (REGROUPED) {
+            const float4 *g4 = reinterpret_cast<const float4 *>(gs + 104 + 2 * c0 + 16 * j);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float4 v = g4[r]; raw[4 * r] = v.x; raw[4 * r + 1] = v.y; raw[4 * r + 2] = v.z; raw[4 * r + 3] = v.w; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) raw[r] = dq_symbol(gs, gt[(2 * c0 + j + 4 * r) & 511]);
+        }
+    };
+    auto commit_chunk = [&](int c0) {
+        if constexpr (REGROUPED) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = dq_soft(gt[(2 * c0 + 16 * j + r) & 511], raw[r], ncor);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                reinterpret_cast<float4 *>(F.ring)[4 * j + r] = make_float4(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) F.ring[j + 4 * r] = dq_soft(gt[(2 * c0 + j + 4 * r) & 511], raw[r], ncor);
+        }
+    };
+
+    // ---- requests: sync symbols, first chunk, LICH symbols
+    float s8[8];
+    if constexpr (REGROUPED) {
+        const float4 a = reinterpret_cast<const float4 *>(gs)[0], b = reinterpret_cast<const float4 *>(gs)[1];
+        s8[0] = a.x; s8[1] = a.y; s8[2] = a.z; s8[3] = a.w; s8[4] = b.x; s8[5] = b.y; s8[6] = b.z; s8[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s8[i] = gs[i];
+    }
+    fetch_chunk(0);
+    float lraw[24];
+    if (type == 2) {
+        if constexpr (REGROUPED) {
+            const float4 *g4 = reinterpret_cast<const float4 *>(gs + 8 + 24 * j);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) { const float4 v = g4[r]; lraw[4 * r] = v.x; lraw[4 * r + 1] = v.y; lraw[4 * r + 2] = v.z; lraw[4 * r + 3] = v.w; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 24; ++k) lraw[k] = dq_symbol(gs, lich[j * 24 + k].e);
+        }
+    }
+    // m17_dsp_demap_frame (m17_dsp.cpp:82-95): amplitude reference from the 8 sync symbols
     {
         float sum = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sum += fabsf(gs[i]);
+        for (int i = 0; i < 8; ++i) sum += fabsf(s8[i]);
         ncor = -(8.0f / sum);                  // cor = (float)(8.0/(double)sum), see limit()
     }
-    reinterpret_cast<uint2 *>(F.bytes)[j] = make_uint2(0u, 0u);
     // ---- LICH (m17_rx_parse.cpp:118-135): quad lane j decodes Golay word j
-    uint32_t gerrs = 0;
+    uint32_t gdata = 0, gpar = 0, genc_v = 0, gerr_v = 0;
     if (type == 2) {
         uint32_t word = 0;
 #pragma unroll
         for (int k = 0; k < 24; ++k) {                                   // hard_decode_24_bits: soft >= 0, as y >= T
             const DqLich L = lich[j * 24 + k];
-            const float nm = dq_symbol(gs, L.e) * ncor;
+            const float nm = lraw[k] * ncor;
             const uint32_t am = (L.e << 21) & 0x80000000u;               // second bit of the dibit: |.|
             const float y = __uint_as_float((__float_as_uint(nm) & ~am) ^ (L.e & 0x80000000u));
             word = (word << 1) | (y >= L.T ? 1u : 0u);
         }
-        int e;
-        const int w = golay_decode(word, genc, gerr, e);
-        const int w0 = dppi<0x00>(w), w1 = dppi<0x55>(w), w2 = dppi<0xAA>(w), w3 = dppi<0xFF>(w);
-        gerrs = (uint32_t)(dppi<0x00>(e) + dppi<0x55>(e) + dppi<0xAA>(e) + dppi<0xFF>(e));
-        group_sync();
-        if (j == 0) {                                                    // pack_12_to_8_x4x6
-            const uint32_t a = ((uint32_t)w0 << 12) | (uint32_t)w1, b = ((uint32_t)w2 << 12) | (uint32_t)w3;
-            F.bytes[0] = (uint8_t)(a >> 16); F.bytes[1] = (uint8_t)(a >> 8); F.bytes[2] = (uint8_t)a;
-            F.bytes[3] = (uint8_t)(b >> 16); F.bytes[4] = (uint8_t)(b >> 8); F.bytes[5] = (uint8_t)b;
-        }
+        gdata = (word >> 12) & 0xFFFu; gpar = word & 0xFFFu;             // m_17_golay_decode (m17_golay.cpp:103-116)
+        genc_v = genc[gdata];                                            // consumed after the first chunk
     }
     STAMP(1);
 
@@ -197,20 +253,8 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__re
         DQ_ACS(n2, a0, a1, "[1,3,1,3]", Mb.x);                                                          \
         DQ_ACS(n1, a2, a3, "[0,2,0,2]", Ma.y);                                                          \
         DQ_ACS(n0, a0, a1, "[0,2,0,2]", Ma.x); } while (0)
-    // soft bits of steps c0 .. c0+31: quad lane j makes ring[j], ring[j+4], ...  (row padded with erasures)
-    float raw[2 * DQ_CHUNK / 4];
-    uint32_t ent[2 * DQ_CHUNK / 4];
-    auto fetch_chunk = [&](int c0) {
-#pragma unroll
-        for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) { ent[r] = gt[(2 * c0 + j + 4 * r) & 511]; raw[r] = dq_symbol(gs, ent[r]); }
-    };
-    auto commit_chunk = [&]() {
-#pragma unroll
-        for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) F.ring[j + 4 * r] = dq_soft(ent[r], raw[r], ncor);
-    };
-    fetch_chunk(0);
-    commit_chunk();
-    group_sync();
+    commit_chunk(0);
+    wave_fence();
     asm volatile("s_nop 1");
     for (int c0 = 0; c0 < steps; c0 += DQ_CHUNK) {
         if (c0 + DQ_CHUNK < steps) fetch_chunk(c0 + DQ_CHUNK);       // in flight during this chunk's butterflies
@@ -226,10 +270,14 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__re
             reinterpret_cast<uint8_t *>(F.dec)[4 * ((c0 >> 1) + t2) + j] = (uint8_t)dw;
             cur = nxt;
         }
-        group_sync();
-        if (c0 + DQ_CHUNK < steps) { commit_chunk(); group_sync(); }
+        wave_fence();
+        if (type == 2 && c0 == 0) gerr_v = gerr[gpar ^ genc_v];        // second Golay table: consumed after the traceback
+        if (c0 + DQ_CHUNK < steps) { commit_chunk(c0 + DQ_CHUNK); wave_fence(); }
         STAMP(3);
     }
+    // the ring has been read for the last time: its place becomes the record payload
+    reinterpret_cast<uint2 *>(F.bytes)[j] = make_uint2(0u, 0u);
+    wave_fence();
 
     // ---- traceback from state 0 (:160-166) and pack_1_to_8(&bits[1], ...) in one go.
     // dword t/2 of dec holds the four lanes' bytes: decision of state s at step t is bit
@@ -259,7 +307,19 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__re
             }
         }
     }
-    group_sync();
+    uint32_t gerrs = 0;
+    if (type == 2) {
+        const int e = (int)((gerr_v & 0xF000u) >> 12);
+        const int w = (int)(gdata ^ (gerr_v & 0xFFFu));
+        const int w0 = dppi<0x00>(w), w1 = dppi<0x55>(w), w2 = dppi<0xAA>(w), w3 = dppi<0xFF>(w);
+        gerrs = (uint32_t)(dppi<0x00>(e) + dppi<0x55>(e) + dppi<0xAA>(e) + dppi<0xFF>(e));
+        if (j == 0) {                                                    // pack_12_to_8_x4x6
+            const uint32_t a = ((uint32_t)w0 << 12) | (uint32_t)w1, b = ((uint32_t)w2 << 12) | (uint32_t)w3;
+            F.bytes[0] = (uint8_t)(a >> 16); F.bytes[1] = (uint8_t)(a >> 8); F.bytes[2] = (uint8_t)a;
+            F.bytes[3] = (uint8_t)(b >> 16); F.bytes[4] = (uint8_t)(b >> 8); F.bytes[5] = (uint8_t)b;
+        }
+    }
+    wave_fence();
     STAMP(4);
     uint32_t fn = 0;
     if (type == 2) fn = ((uint32_t)F.bytes[6] << 8) | F.bytes[7];                     // pack_8_to_16
@@ -273,23 +333,30 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrame &F, const float *__re
             r[1] = (r[1] & 0x0000FFFFu) | (fn << 16);
         }
     }
-    group_sync();
+    wave_fence();
 }
 
-// work != nullptr: lists per type (work[3][cap], nwork[3]); else plain batch: frame i of
-// n_plain, type from types[i], record i
-__global__ __launch_bounds__(64)
+// ONLY == 0: any frame type, one wave per workgroup.  work != nullptr: lists per type (work[3][cap], nwork[3]; the
+//            stream list is left out when skip_stream is set); else plain batch: frame i of n_plain, type from
+//            types[i], record i.
+// ONLY == 2: the stream work list alone, with the per-frame LDS sized for 148 trellis steps: four waves per
+//            workgroup (each on its own 16 frames) share the tables, four workgroups = 16 waves fit a CU.
+template <int ONLY>
+__global__ __launch_bounds__(ONLY == 2 ? 256 : 64, ONLY == 2 ? 4 : 1)
 void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ work,
                    const int32_t *__restrict__ nwork, int cap,
                    const uint8_t *__restrict__ types, int n_plain,
                    m17gpu_rec_dev *__restrict__ recs,
-                   const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr)
+                   const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr, int skip_stream,
+                   int slot_floats)
 {
-    __shared__ __attribute__((aligned(16))) QuadFrame fr[DQ_FRAMES];        // 12.3 KB (+2 KB table): eleven waves per CU
+    constexpr int WAVES = (ONLY == 2) ? 4 : 1;
+    using Frame = QuadFrameT<(ONLY == 2) ? DQ_DECW_STREAM : DQ_DECW>;
+    __shared__ __attribute__((aligned(16))) Frame fr[WAVES][DQ_FRAMES];     // 8.75 KB (stream) / 11.75 KB per wave
     __shared__ uint32_t gt_row[512];                                        // DevTables.gather row of the current type, re-coded
-    const DqLich *lich_row = c_tab.lich_q;                                  // lane-indexed: vector loads, cache-resident
-    const int lane = lane_id(), q = lane >> 2, j = lane & 3;
-    QuadFrame &F = fr[q];
+    __shared__ DqLich lich_row[96];
+    const int lane = lane_id(), q = lane >> 2, j = lane & 3, wave = (int)(threadIdx.x >> 6);
+    Frame &F = fr[wave][q];
 
     // per-lane constants of the butterfly: state v = 4j+i, even predecessor's metric index
     // metric[idx] = (idx & 2 ? m1 : -m1) + (idx & 1 ? m2 : -m2)  (m17_conv.cpp:88-91) = c1 * m1 + c2 * m2 with c = +-1:
@@ -302,61 +369,89 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
         if (i & 1) { C1[i >> 1].y = c1; C2[i >> 1].y = c2; } else { C1[i >> 1].x = c1; C2[i >> 1].x = c2; }
     }
 
+    // nothing to do for this workgroup (no frame of these types this call, or more workgroups than tasks): leave
+    // before the tables are filled -- the any-type kernel normally finds its lists empty
+    {
+        int m1 = 0, m2 = 0, m3 = 0;
+        if (work) { m1 = nwork[0]; m2 = nwork[1]; m3 = nwork[2]; }
+        if (ONLY == 0 && skip_stream) m2 = 0;
+        const int tasks = ONLY ? (m2 + DQ_FRAMES - 1) / DQ_FRAMES
+                               : (work ? (m1 + DQ_FRAMES - 1) / DQ_FRAMES + (m2 + DQ_FRAMES - 1) / DQ_FRAMES + (m3 + DQ_FRAMES - 1) / DQ_FRAMES
+                                       : (n_plain + DQ_FRAMES - 1) / DQ_FRAMES);
+        if ((int)blockIdx.x * WAVES >= tasks) return;
+    }
+    for (int i = (int)threadIdx.x; i < 96; i += 64 * WAVES) lich_row[i] = c_tab.lich_q[i];
     int row_type = 0;
+    if (ONLY) {
+        for (int i = (int)threadIdx.x; i < 512; i += 64 * WAVES) gt_row[i] = dq_entry((i < 488) ? (int)c_tab.gather[ONLY][i] : -1);
+        row_type = ONLY;
+    }
+    __syncthreads();                                                        // the only workgroup barrier: tables are read-only from here
+
     int n1 = 0, n2 = 0, n3 = 0;
     if (work) { n1 = nwork[0]; n2 = nwork[1]; n3 = nwork[2]; }
+    if (ONLY == 0 && skip_stream) n2 = 0;
     const int t2 = (n2 + DQ_FRAMES - 1) / DQ_FRAMES, t1 = (n1 + DQ_FRAMES - 1) / DQ_FRAMES,
               t3 = (n3 + DQ_FRAMES - 1) / DQ_FRAMES;
-    const int ntask = uni(work ? (t2 + t1 + t3) : (n_plain + DQ_FRAMES - 1) / DQ_FRAMES);
+    const int ntask = uni(ONLY ? t2 : (work ? (t2 + t1 + t3) : (n_plain + DQ_FRAMES - 1) / DQ_FRAMES));
+    const int stride = (int)gridDim.x * WAVES;
+
+    // the frame a quad works on in task `task` (work-list mode): list, index and whether it exists
+    auto pick = [&](int task, int &qtype, bool &active) -> size_t {
+        int seg, base, n;
+        if (ONLY || task < t2) { seg = 1; base = task * DQ_FRAMES; n = n2; }               // stream frames first
+        else if (task < t2 + t1) { seg = 0; base = (task - t2) * DQ_FRAMES; n = n1; }
+        else { seg = 2; base = (task - t2 - t1) * DQ_FRAMES; n = n3; }
+        active = base + q < n;
+        qtype = seg + 1;
+        return (size_t)seg * cap + (active ? base + q : n - 1);
+    };
 
     unsigned long long acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, last_ = 0;
 #ifdef M17_STAMPS
     last_ = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    for (int task = (int)blockIdx.x; task < ntask; task += (int)gridDim.x) {
+    int task = (int)blockIdx.x * WAVES + wave;
+    int slot_next = 0;
+    if (work && task < ntask) { int qt; bool ac; slot_next = work[pick(task, qt, ac)]; }
+    for (; task < ntask; task += stride) {
         STAMP(6);
-        // ---- which frame
+        // ---- which frame (the work-list entry was requested one task ahead)
         int qtype, slot; bool active;
         if (work) {
-            int seg, base, n;
-            if (task < t2) { seg = 1; base = task * DQ_FRAMES; n = n2; }                    // stream frames first
-            else if (task < t2 + t1) { seg = 0; base = (task - t2) * DQ_FRAMES; n = n1; }
-            else { seg = 2; base = (task - t2 - t1) * DQ_FRAMES; n = n3; }
-            active = base + q < n;
-            slot = work[(size_t)seg * cap + (active ? base + q : n - 1)];
-            qtype = seg + 1;
+            (void)pick(task, qtype, active);
+            slot = slot_next;
+            if (task + stride < ntask) { int qt; bool ac; slot_next = work[pick(task + stride, qt, ac)]; }
         } else {
             const int item = task * DQ_FRAMES + q;
             active = item < n_plain;
             slot = active ? item : n_plain - 1;
             qtype = (int)types[slot];
         }
-        const float *gs = fsym + (size_t)slot * kFrameSyms;          // the frame's symbols, read in place
+        const float *gs = fsym + (size_t)slot * slot_floats;         // the frame's slot, read in place
         m17gpu_rec_dev *rec = &recs[slot];
         const uint32_t r0_keep = work ? reinterpret_cast<const uint32_t *>(rec)[0] : (uint32_t)qtype;
-        group_sync();
         STAMP(0);
+        if (ONLY) {
+            decode_quad_pass<Frame::kDecw, ONLY>(F, gs, gt_row, lich_row, ONLY, j, active, r0_keep, rec, C1, C2, genc, gerr, acc_, last_);
+        } else {
 #pragma unroll 1
-        for (int pass = 0; pass < 3; ++pass) {
-            const int type = (pass == 0) ? 2 : (pass == 1 ? 1 : 3);
-            if (__ballot(qtype == type) == 0ull) continue;
-            if (row_type != type) {
-                for (int i = lane; i < 512; i += 64) {
-                    gt_row[i] = dq_entry((i < 488) ? (int)c_tab.gather[type][i] : -1);
-#ifdef DQ_ABL_COALESCED
-                    gt_row[i] = (gt_row[i] & ~0x3FFu) | (4u * (8u + (uint32_t)(i % 184)));
-#endif
+            for (int pass = 0; pass < 3; ++pass) {
+                const int type = (pass == 0) ? 2 : (pass == 1 ? 1 : 3);
+                if (__ballot(qtype == type) == 0ull) continue;
+                if (row_type != type) {
+                    for (int i = lane; i < 512; i += 64) gt_row[i] = dq_entry((i < 488) ? (int)c_tab.gather[type][i] : -1);
+                    row_type = type;
+                    wave_fence();
                 }
-                row_type = type;
-                group_sync();
+                decode_quad_pass<Frame::kDecw, 0>(F, gs, gt_row, lich_row, type, j, active && qtype == type, r0_keep, rec, C1, C2, genc, gerr, acc_, last_);
             }
-            decode_quad_pass(F, gs, gt_row, lich_row, type, j, active && qtype == type, r0_keep, rec, C1, C2, genc, gerr, acc_, last_);
         }
         STAMP(5);
     }
 #ifdef M17_STAMPS
-    if (blockIdx.x == 0 && lane == 0) { for (int i = 0; i < 7; ++i) g_stamps[i] = acc_[i]; g_stamps[8] = (unsigned long long)ntask; }
+    if (ONLY == 2 && blockIdx.x == 0 && threadIdx.x == 0) { for (int i = 0; i < 7; ++i) g_stamps[i] = acc_[i]; g_stamps[8] = (unsigned long long)ntask; }
 #endif
 }
 

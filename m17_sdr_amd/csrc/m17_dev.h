@@ -8,6 +8,14 @@ namespace m17dev {
 constexpr int kBlockSamples = 1920;   // m17defines.h:17
 constexpr int kDiscOut      = 384;    // m17_dsp.cpp:463
 constexpr int kFrameSyms    = 192;    // m17defines.h:66
+// One frame slot of the decoder's workspace.  Link-setup and packet frames are stored as their 192 symbols.  A stream
+// frame is stored in the order its decoder reads it (DevTables.regroup), so that the decoder's loads are contiguous --
+// gathered from the plain 192 symbols, every soft bit cost an L2 round trip of a whole cache line:
+//   [0,8) sync symbols; [8,104) the source symbols of the 96 LICH soft bits; [104,400) those of the 296 de-punctured
+//   payload soft bits (an erasure's place holds some symbol, never used); [400,424) not written (the last 32-step
+//   chunk reads it and masks it out).
+constexpr int kSlotFloats   = 424;
+constexpr int kRegroup      = 392;
 constexpr int kSoftBits     = 368;
 constexpr int kPhases       = 40;     // m17_rx_sync.cpp:3
 constexpr int kTaps         = 31;     // m17_rx_sync.cpp:4
@@ -88,6 +96,7 @@ struct DevTables {
     int16_t  gather[4][488];         // -1 erasure, else src | 0x4000 when negated
     int16_t  lich[96];
     DqLich   lich_q[96];             // lich[] as the decoder reads it
+    alignas(4) uint8_t regroup[kRegroup];   // stream frame slot: payload symbol (0..183) behind slot entry 8 + i
     int16_t  glen[4];
     uint8_t  bm_even[16], bm_odd[16];
     uint16_t crc[256];

@@ -24,6 +24,54 @@ __device__ __forceinline__ void wave_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
+// A completed frame into its slot of the decoder's workspace (m17_dev.h: kSlotFloats).  src(q) is symbol q of the
+// frame.  Lane gl of a channel's LPC lanes writes slot entries 8 + 4 (gl + LPC r) + {0..3} as one 16-byte store; which
+// symbols go there is fixed per lane, so the lane keeps those table bytes packed in registers for the whole kernel
+// (a table in LDS put two dependent LDS round trips in front of every batch of stores).
+template <int LPC> struct RegroupLane {
+    static constexpr int R = (kRegroup / 4 + LPC - 1) / LPC;          // 16-byte groups per lane: 7 / 4 / 2
+    uint32_t w[R];
+    __device__ __forceinline__ void load(int gl)
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int q = 4 * (gl + LPC * r);
+            w[r] = (q < kRegroup) ? *reinterpret_cast<const uint32_t *>(&c_tab.regroup[q]) : 0u;
+        }
+    }
+    __device__ __forceinline__ int sym(int r, int c) const { return 8 + (int)((w[r] >> (8 * c)) & 0xFFu); }
+};
+template <int LPC, class Src>
+__device__ __forceinline__ void store_frame_slot(float *__restrict__ fd, int type, int gl, const RegroupLane<LPC> &rg, Src src)
+{
+    if (type == 2) {
+        if (gl < 8) fd[gl] = src(gl);
+        constexpr int R = RegroupLane<LPC>::R;
+        float4 t[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) t[r] = make_float4(src(rg.sym(r, 0)), src(rg.sym(r, 1)), src(rg.sym(r, 2)), src(rg.sym(r, 3)));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int q = 4 * (gl + LPC * r);
+            if (q < kRegroup) *reinterpret_cast<float4 *>(fd + 8 + q) = t[r];
+        }
+    } else {
+        constexpr int R = (kFrameSyms / 4 + LPC - 1) / LPC;            // 3 / 2 / 1
+        float4 t[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int q = 4 * (gl + LPC * r);
+            const int qq = q < kFrameSyms ? q : 0;
+            t[r] = make_float4(src(qq), src(qq + 1), src(qq + 2), src(qq + 3));
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int q = 4 * (gl + LPC * r);
+            if (q < kFrameSyms) *reinterpret_cast<float4 *>(fd + q) = t[r];
+        }
+    }
+}
+
 // candidate pre-filter of the sync hunt: m17_unlocked_sync_check needs votes == 0 for
 // the winning template, i.e. no symbol of the window may have the sign OPPOSITE to
 // that template (zeros and NaNs never vote, m17_rx_frame.cpp:77-80).  A window that

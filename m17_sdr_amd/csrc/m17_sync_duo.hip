@@ -225,6 +225,8 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
     int nrec = (b0 == 0) ? 0 : counts[chan];
     int sym_total = (b0 == 0) ? 0 : cs.sym_total;
     int hp = 256;
+    RegroupLane<LPC> rg;
+    rg.load(gl);
     // m_f_sym[0 .. fclk) is the frame in progress: ring [hp - fclk, hp); m_sync is the last 8 symbols.
     // Only positions below hp are written here: hp upward belongs to the timing wave from the start.
     if (flock) { for (int q = gl; q < fclk; q += LPC) my.H[(hp - fclk + q) & (kDuoRing - 1)] = cs.fsym[q]; }
@@ -272,8 +274,8 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                     const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
                     emit_record_grp(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
                     if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
-                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kFrameSyms;
-                        for (int q = gl; q < kFrameSyms; q += LPC) fd[q] = my.H[(fs + q) & (kDuoRing - 1)];
+                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kSlotFloats;
+                        store_frame_slot<LPC>(fd, r.type, gl, rg, [&](int q) { return my.H[(fs + q) & (kDuoRing - 1)]; });
                     }
                     nrec++;
                     if (unlock) {

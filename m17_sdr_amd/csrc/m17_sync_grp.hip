@@ -243,6 +243,8 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
     m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
     if (!recs) rec_cap = 0;
     const unsigned long long incl = (gl == 63) ? ~0ull : ((2ull << gl) - 1ull);
+    RegroupLane<LPC> rg;
+    rg.load(gl);
 
     // group-uniform control state, one copy per lane
     int clk = cs.clk, thr = cs.thr, index = cs.index;
@@ -386,13 +388,8 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
                     const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
                     emit_record_grp(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
                     if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
-                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kFrameSyms;
-                        constexpr int R = kFrameSyms / LPC;
-                        float t[R];
-#pragma unroll
-                        for (int r = 0; r < R; ++r) t[r] = my.f[gl + LPC * r];
-#pragma unroll
-                        for (int r = 0; r < R; ++r) fd[gl + LPC * r] = t[r];
+                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kSlotFloats;
+                        store_frame_slot<LPC>(fd, r.type, gl, rg, [&](int q) { return my.f[q]; });
                     }
                     nrec++;
                     if (unlock) {

@@ -99,6 +99,10 @@ int upload_tables(m17gpu_ctx *ctx)
         h.lich[j] = (int16_t)(T.lich_src[j] | (T.lich_sign[j] < 0 ? 0x4000 : 0));
         h.lich_q[j] = dq_lich_entry((int)h.lich[j]);
     }
+    for (int i = 0; i < kRegroup; ++i) {
+        const int g = (i < 96) ? (int)h.lich[i] : (int)h.gather[2][i - 96];
+        h.regroup[i] = (uint8_t)(g < 0 ? 0 : ((g & 0x3FF) >> 1));
+    }
     std::memcpy(h.bm_even, T.bm_even, 16);
     std::memcpy(h.bm_odd, T.bm_odd, 16);
     std::memcpy(h.crc, T.crc, sizeof h.crc);
@@ -173,7 +177,7 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
     int32_t *counts = (d_counts ? d_counts : ctx->d_counts) + c0;
     float *syms = d_syms ? d_syms + (size_t)c0 * M17_SYM_STRIDE(nblk) : nullptr;
     int32_t *nsyms = d_nsyms ? d_nsyms + (size_t)c0 * nblk : nullptr;
-    float *fsym = ctx->d_fsym + (size_t)c0 * rec_cap * kFrameSyms;
+    float *fsym = ctx->d_fsym + (size_t)c0 * rec_cap * kSlotFloats;
     // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
     int lpc = ctx->lanes_per_channel;
     if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
@@ -202,16 +206,23 @@ int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_c
 {
     m17gpu_rec_dev *recs = reinterpret_cast<m17gpu_rec_dev *>(d_recs) + (size_t)c0 * rec_cap;
     int32_t *cnt = (d_counts ? d_counts : ctx->d_counts) + c0;
-    float *fsym = ctx->d_fsym + (size_t)c0 * rec_cap * kFrameSyms;
+    float *fsym = ctx->d_fsym + (size_t)c0 * rec_cap * kSlotFloats;
     int32_t *work = ctx->d_work + 3 * (size_t)c0 * ctx->rec_cap_max;
     int32_t *nwork = ctx->d_nwork + 4 * chunk;
     const long long slots = (long long)cn * rec_cap;
     hipLaunchKernelGGL(k_worklist, dim3(cdiv(slots, 1024)), dim3(1024), 0, st, recs, rec_cap, cnt, cn,
                        work, nwork, (int)slots);
-    int grid = cdiv(slots, DQ_FRAMES) + 3;
-    if (grid > 256 * 11) grid = 256 * 11;                    // 11 single-wave workgroups per CU by LDS
-    hipLaunchKernelGGL(k_decode_quad, dim3(grid), dim3(64), 0, st, fsym, work, nwork,
-                       (int)slots, (const uint8_t *)nullptr, 0, recs, ctx->d_genc, ctx->d_gerr);
+    // stream frames (the bulk of any traffic) on the kernel sized for them, four waves per workgroup and four
+    // workgroups per CU; link-setup and packet frames on the any-type kernel (13 single-wave workgroups per CU by LDS)
+    int grid = cdiv(cdiv(slots, DQ_FRAMES) + 1, 4);
+    if (grid > 256 * 4) grid = 256 * 4;
+    hipLaunchKernelGGL(k_decode_quad<2>, dim3(grid), dim3(256), 0, st, fsym, work, nwork,
+                       (int)slots, (const uint8_t *)nullptr, 0, recs, ctx->d_genc, ctx->d_gerr, 0, kSlotFloats);
+    HIPCHK(hipGetLastError());
+    grid = cdiv(slots, DQ_FRAMES) + 2;
+    if (grid > 256 * 13) grid = 256 * 13;
+    hipLaunchKernelGGL(k_decode_quad<0>, dim3(grid), dim3(64), 0, st, fsym, work, nwork,
+                       (int)slots, (const uint8_t *)nullptr, 0, recs, ctx->d_genc, ctx->d_gerr, 1, kSlotFloats);
     HIPCHK(hipGetLastError());
     if (ev_mid) HIPCHK(hipEventRecord(ev_mid, st));
     hipLaunchKernelGGL(k_book_chan, dim3(cn), dim3(64), 0, st, ctx->d_state + c0, recs, rec_cap, cnt, ctx->d_crc_basis);
@@ -258,7 +269,7 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     ALLOC(ctx->d_state, sizeof(ChanState) * (size_t)n_channels);
     ALLOC(ctx->d_disc, sizeof(float) * cb * kDiscOut);
     ALLOC(ctx->d_offs, sizeof(float) * cb);
-    ALLOC(ctx->d_fsym, sizeof(float) * (size_t)n_channels * ctx->rec_cap_max * kFrameSyms);
+    ALLOC(ctx->d_fsym, sizeof(float) * (size_t)n_channels * ctx->rec_cap_max * kSlotFloats);
     ALLOC(ctx->d_work, sizeof(int32_t) * 3 * (size_t)n_channels * ctx->rec_cap_max);   // one list per frame type (decode_impl 2)
     ALLOC(ctx->d_nwork, sizeof(int32_t) * 4);
     ALLOC(ctx->d_counts, sizeof(int32_t) * (size_t)n_channels);
@@ -600,10 +611,10 @@ int m17gpu_decode_frames(m17gpu_ctx *ctx, const float *d_sym, const uint8_t *d_t
     hipStream_t st = S(stream);
     HIPCHK(hipMemsetAsync(d_recs, 0, sizeof(m17gpu_rec) * (size_t)n, st));
     int grid = cdiv(n, DQ_FRAMES);
-    if (grid > 256 * 11) grid = 256 * 11;
-    hipLaunchKernelGGL(k_decode_quad, dim3(grid), dim3(64), 0, st, d_sym, (const int32_t *)nullptr,
+    if (grid > 256 * 13) grid = 256 * 13;
+    hipLaunchKernelGGL(k_decode_quad<0>, dim3(grid), dim3(64), 0, st, d_sym, (const int32_t *)nullptr,
                        (const int32_t *)nullptr, 0, d_type, n, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
-                       ctx->d_genc, ctx->d_gerr);
+                       ctx->d_genc, ctx->d_gerr, 0, kFrameSyms);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
