@@ -348,7 +348,14 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
     };
     const uint4 *g0 = row_ptr(0), *g1 = row_ptr(1), *g2 = row_ptr(2), *g3 = row_ptr(3);
     const int l0 = lr * FQ_STRIDE + c16 * 4, l1 = l0 + 4 * FQ_STRIDE, l2 = l0 + 8 * FQ_STRIDE, l3 = l0 + 12 * FQ_STRIDE;
-    uint4 s0 = g0[0], s1 = g1[0], s2 = g2[0], s3 = g3[0];
+    // the IQ stream is read exactly once: non-temporal, so that it does not evict the discriminator stream the
+    // timing stage is about to re-read from the cache levels below
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    auto ld = [](const uint4 *p) {
+        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    uint4 s0 = ld(g0), s1 = ld(g1), s2 = ld(g2), s3 = ld(g3);
 
     float offset = 0.0f;
     float *dst = disc_raw + (size_t)cb * kDiscOut;
@@ -362,7 +369,7 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
         *reinterpret_cast<uint4 *>(&my[l3]) = s3;
         {
             const int nx = ((chunk + 1 < FQ_NCHUNK) ? chunk + 1 : chunk) * (FQ_CHUNK / 4);
-            s0 = g0[nx]; s1 = g1[nx]; s2 = g2[nx]; s3 = g3[nx];
+            s0 = ld(g0 + nx); s1 = ld(g1 + nx); s2 = ld(g2 + nx); s3 = ld(g3 + nx);
         }
         wave_lds_sync();
         uint32_t w[16];

@@ -110,7 +110,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                 const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
                 noff = osrc ? osrc[b + 1] : 0.0f;
 #pragma unroll
-                for (int r = 0; r < PF; ++r) pf[r] = nx[gl + LPC * r];
+                for (int r = 0; r < PF; ++r) pf[r] = __builtin_nontemporal_load(&nx[gl + LPC * r]);   // read once
             }
             const int s_clk = clk, s_thr = thr, s_index = index;
             const float s_sum = sum, s_dif = dif;

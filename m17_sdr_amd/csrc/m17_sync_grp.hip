@@ -334,7 +334,7 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
             const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
             noff = osrc ? osrc[b + 1] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < PF; ++r) pf[r] = nx[gl + LPC * r];
+            for (int r = 0; r < PF; ++r) pf[r] = __builtin_nontemporal_load(&nx[gl + LPC * r]);   // read once
         }
 
         // symbols out (optional)
@@ -345,7 +345,7 @@ void k_sync_frame_grp(const float *__restrict__ disc,     // [C][nblk][384]
 #pragma unroll
             for (int r = 0; r < (193 + LPC - 1) / LPC; ++r) {
                 const int q = gl + LPC * r;
-                if (q < n) so[q] = my.h[8 + q];
+                if (q < n) __builtin_nontemporal_store(my.h[8 + q], &so[q]);     // output, not read again here
             }
         }
         if (nsyms && gl == 0) nsyms[(size_t)chan * nblk + b] = n;
