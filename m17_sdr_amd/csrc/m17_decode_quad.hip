@@ -336,27 +336,34 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW> &F, const floa
     wave_fence();
 }
 
-// ONLY == 0: any frame type, one wave per workgroup.  work != nullptr: lists per type (work[3][cap], nwork[3]; the
-//            stream list is left out when skip_stream is set); else plain batch: frame i of n_plain, type from
-//            types[i], record i.
-// ONLY == 2: the stream work list alone, with the per-frame LDS sized for 148 trellis steps: four waves per
-//            workgroup (each on its own 16 frames) share the tables, four workgroups = 16 waves fit a CU.
-template <int ONLY>
-__global__ __launch_bounds__(ONLY == 2 ? 256 : 64, ONLY == 2 ? 4 : 1)
-void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ work,
+// Workgroup-shared storage of the decoder for WAVES waves, each on its own 16 frames.
+// ONLY == 2: stream frames only: per-frame LDS sized for 148 trellis steps, one shared table row.
+// ONLY == 0: any frame type, a table row per wave.
+template <int ONLY, int WAVES>
+struct alignas(16) DqShared {
+    QuadFrameT<(ONLY == 2) ? DQ_DECW_STREAM : DQ_DECW> fr[WAVES][DQ_FRAMES];   // 8.75 KB (stream) / 11.75 KB per wave
+    uint32_t gt_rows[ONLY ? 1 : WAVES][512];                                   // DevTables.gather row of the current type, re-coded
+    DqLich   lich_row[96];
+};
+
+// The decoder as workgroup number wg of n_wg workgroups of WAVES waves (threads beyond 64 * WAVES must not enter).
+// work != nullptr: lists per type (work[3][cap], nwork[3]; ONLY == 2 takes the stream list, ONLY == 0 all of them or,
+// with skip_stream, all but the stream list); else (ONLY == 0) plain batch: frame i of n_plain, type from types[i],
+// record i.
+template <int ONLY, int WAVES>
+__device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES> &sh, int wg, int n_wg,
+                   const float *__restrict__ fsym, const int32_t *__restrict__ work,
                    const int32_t *__restrict__ nwork, int cap,
                    const uint8_t *__restrict__ types, int n_plain,
                    m17gpu_rec_dev *__restrict__ recs,
                    const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr, int skip_stream,
                    int slot_floats)
 {
-    constexpr int WAVES = (ONLY == 2) ? 4 : 1;
     using Frame = QuadFrameT<(ONLY == 2) ? DQ_DECW_STREAM : DQ_DECW>;
-    __shared__ __attribute__((aligned(16))) Frame fr[WAVES][DQ_FRAMES];     // 8.75 KB (stream) / 11.75 KB per wave
-    __shared__ uint32_t gt_row[512];                                        // DevTables.gather row of the current type, re-coded
-    __shared__ DqLich lich_row[96];
     const int lane = lane_id(), q = lane >> 2, j = lane & 3, wave = (int)(threadIdx.x >> 6);
-    Frame &F = fr[wave][q];
+    Frame &F = sh.fr[wave][q];
+    uint32_t *gt_row = sh.gt_rows[ONLY ? 0 : wave];
+    DqLich *lich_row = sh.lich_row;
 
     // per-lane constants of the butterfly: state v = 4j+i, even predecessor's metric index
     // metric[idx] = (idx & 2 ? m1 : -m1) + (idx & 1 ? m2 : -m2)  (m17_conv.cpp:88-91) = c1 * m1 + c2 * m2 with c = +-1:
@@ -378,7 +385,7 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
         const int tasks = ONLY ? (m2 + DQ_FRAMES - 1) / DQ_FRAMES
                                : (work ? (m1 + DQ_FRAMES - 1) / DQ_FRAMES + (m2 + DQ_FRAMES - 1) / DQ_FRAMES + (m3 + DQ_FRAMES - 1) / DQ_FRAMES
                                        : (n_plain + DQ_FRAMES - 1) / DQ_FRAMES);
-        if ((int)blockIdx.x * WAVES >= tasks) return;
+        if (wg * WAVES >= tasks) return;
     }
     for (int i = (int)threadIdx.x; i < 96; i += 64 * WAVES) lich_row[i] = c_tab.lich_q[i];
     int row_type = 0;
@@ -394,7 +401,7 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
     const int t2 = (n2 + DQ_FRAMES - 1) / DQ_FRAMES, t1 = (n1 + DQ_FRAMES - 1) / DQ_FRAMES,
               t3 = (n3 + DQ_FRAMES - 1) / DQ_FRAMES;
     const int ntask = uni(ONLY ? t2 : (work ? (t2 + t1 + t3) : (n_plain + DQ_FRAMES - 1) / DQ_FRAMES));
-    const int stride = (int)gridDim.x * WAVES;
+    const int stride = n_wg * WAVES;
 
     // the frame a quad works on in task `task` (work-list mode): list, index and whether it exists
     auto pick = [&](int task, int &qtype, bool &active) -> size_t {
@@ -412,7 +419,7 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
     last_ = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    int task = (int)blockIdx.x * WAVES + wave;
+    int task = wg * WAVES + wave;
     int slot_next = 0;
     if (work && task < ntask) { int qt; bool ac; slot_next = work[pick(task, qt, ac)]; }
     for (; task < ntask; task += stride) {
@@ -451,8 +458,45 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
         STAMP(5);
     }
 #ifdef M17_STAMPS
-    if (ONLY == 2 && blockIdx.x == 0 && threadIdx.x == 0) { for (int i = 0; i < 7; ++i) g_stamps[i] = acc_[i]; g_stamps[8] = (unsigned long long)ntask; }
+    if (ONLY == 2 && wg == 0 && threadIdx.x == 0) { for (int i = 0; i < 7; ++i) g_stamps[i] = acc_[i]; g_stamps[8] = (unsigned long long)ntask; }
 #endif
+}
+
+// Plain-batch entry and A/B: one role per launch, four waves per workgroup.
+template <int ONLY>
+__global__ __launch_bounds__(256, ONLY == 2 ? 4 : 2)
+void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ work,
+                   const int32_t *__restrict__ nwork, int cap,
+                   const uint8_t *__restrict__ types, int n_plain,
+                   m17gpu_rec_dev *__restrict__ recs,
+                   const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr, int skip_stream,
+                   int slot_floats)
+{
+    __shared__ DqShared<ONLY, 4> sh;
+    decode_quad_body<ONLY, 4>(sh, (int)blockIdx.x, (int)gridDim.x, fsym, work, nwork, cap, types, n_plain, recs, genc, gerr,
+                              skip_stream, slot_floats);
+}
+
+// The work lists of one m17gpu_rx_blocks call in ONE launch.  Workgroups [0, n_other) take the link-setup and packet
+// lists on two of their four waves (any-type storage for two waves fits the LDS the stream role needs for four), the
+// rest the stream list.  A lone link-setup frame costs a wave the latency of a whole 244-step task (~40 us): in a
+// launch of its own, behind the stream launch, that was 38 us added to every call; here it runs beside the stream
+// tasks.  The any-type workgroups come first so that they are placed at once; with their lists empty they leave
+// before touching their tables.
+__global__ __launch_bounds__(256, 4)
+void k_decode_lists(const float *__restrict__ fsym, const int32_t *__restrict__ work,
+                    const int32_t *__restrict__ nwork, int cap, m17gpu_rec_dev *__restrict__ recs,
+                    const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr, int slot_floats, int n_other)
+{
+    __shared__ union U { DqShared<2, 4> s; DqShared<0, 2> o; __device__ U() {} } sh;
+    static_assert(sizeof(DqShared<0, 2>) <= sizeof(DqShared<2, 4>), "the any-type role must fit the stream role's LDS");
+    if ((int)blockIdx.x < n_other) {
+        if (threadIdx.x >= 128) return;
+        decode_quad_body<0, 2>(sh.o, (int)blockIdx.x, n_other, fsym, work, nwork, cap, nullptr, 0, recs, genc, gerr, 1, slot_floats);
+    } else {
+        decode_quad_body<2, 4>(sh.s, (int)blockIdx.x - n_other, (int)gridDim.x - n_other, fsym, work, nwork, cap, nullptr, 0,
+                               recs, genc, gerr, 0, slot_floats);
+    }
 }
 
 } // namespace m17dev

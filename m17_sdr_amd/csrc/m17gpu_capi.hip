@@ -212,17 +212,15 @@ int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_c
     const long long slots = (long long)cn * rec_cap;
     hipLaunchKernelGGL(k_worklist, dim3(cdiv(slots, 1024)), dim3(1024), 0, st, recs, rec_cap, cnt, cn,
                        work, nwork, (int)slots);
-    // stream frames (the bulk of any traffic) on the kernel sized for them, four waves per workgroup and four
-    // workgroups per CU; link-setup and packet frames on the any-type kernel (13 single-wave workgroups per CU by LDS)
-    int grid = cdiv(cdiv(slots, DQ_FRAMES) + 1, 4);
+    // one launch for all three lists (k_decode_lists): stream frames, the bulk of any traffic, on four workgroups of
+    // four waves per CU; link-setup and packet frames on up to 512 leading workgroups
+    const int tasks = cdiv(slots, DQ_FRAMES) + 2;
+    int n_other = cdiv(tasks, 2);
+    if (n_other > 512) n_other = 512;
+    int grid = cdiv(tasks, 4);
     if (grid > 256 * 4) grid = 256 * 4;
-    hipLaunchKernelGGL(k_decode_quad<2>, dim3(grid), dim3(256), 0, st, fsym, work, nwork,
-                       (int)slots, (const uint8_t *)nullptr, 0, recs, ctx->d_genc, ctx->d_gerr, 0, kSlotFloats);
-    HIPCHK(hipGetLastError());
-    grid = cdiv(slots, DQ_FRAMES) + 2;
-    if (grid > 256 * 13) grid = 256 * 13;
-    hipLaunchKernelGGL(k_decode_quad<0>, dim3(grid), dim3(64), 0, st, fsym, work, nwork,
-                       (int)slots, (const uint8_t *)nullptr, 0, recs, ctx->d_genc, ctx->d_gerr, 1, kSlotFloats);
+    hipLaunchKernelGGL(k_decode_lists, dim3(grid + n_other), dim3(256), 0, st, fsym, work, nwork, (int)slots, recs,
+                       ctx->d_genc, ctx->d_gerr, kSlotFloats, n_other);
     HIPCHK(hipGetLastError());
     if (ev_mid) HIPCHK(hipEventRecord(ev_mid, st));
     hipLaunchKernelGGL(k_book_chan, dim3(cn), dim3(64), 0, st, ctx->d_state + c0, recs, rec_cap, cnt, ctx->d_crc_basis);
@@ -610,9 +608,9 @@ int m17gpu_decode_frames(m17gpu_ctx *ctx, const float *d_sym, const uint8_t *d_t
     ON_CTX_DEVICE(ctx);
     hipStream_t st = S(stream);
     HIPCHK(hipMemsetAsync(d_recs, 0, sizeof(m17gpu_rec) * (size_t)n, st));
-    int grid = cdiv(n, DQ_FRAMES);
-    if (grid > 256 * 13) grid = 256 * 13;
-    hipLaunchKernelGGL(k_decode_quad<0>, dim3(grid), dim3(64), 0, st, d_sym, (const int32_t *)nullptr,
+    int grid = cdiv(cdiv(n, DQ_FRAMES), 4);
+    if (grid > 256 * 2) grid = 256 * 2;
+    hipLaunchKernelGGL(k_decode_quad<0>, dim3(grid), dim3(256), 0, st, d_sym, (const int32_t *)nullptr,
                        (const int32_t *)nullptr, 0, d_type, n, reinterpret_cast<m17gpu_rec_dev *>(d_recs),
                        ctx->d_genc, ctx->d_gerr, 0, kFrameSyms);
     HIPCHK(hipGetLastError());
