@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-fir-stage", action="store_true", help="skip the nested configs[1] FIR-stage measurement")
     ap.add_argument("--no-fanout", action="store_true", help="N>1: skip the separately timed RCCL scatter/gather legs")
     ap.add_argument("--no-syms", action="store_true", help="front end: do not write the symbol stream")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="m17gpu_set_option on the receiver (A/B of bit-identical kernel variants; recorded in config)")
     args = ap.parse_args(argv)
     if args.channels is None:
         args.channels = 16384 if args.workload == "full" else 1024
@@ -288,6 +290,9 @@ def run_rank(args):
     mode = 0 if args.workload == "frontend" else 1
     T = args.warmup + args.steps
     rx = m.Receiver(C, nblk, device=local)
+    for kv in args.option:
+        name, value = kv.split("=")
+        rx.set_option(name, int(value))
     iq, sig, Tg = make_input(args, rank, torch, rx, C, nblk, T)
     out = rx.alloc_outputs(nblk, want_syms=(mode == 0 and not args.no_syms))
 
@@ -340,6 +345,8 @@ def run_rank(args):
                    "parallelism": f"channel-sharded x{world}, one process per GPU, no data-path collective in the timed region"},
         "roofline": roofline_obj(kms, ncalls, mode, C * nblk, f"{args.workload}:{C}x{nblk}"),
     }
+    if args.option:
+        line["config"]["options"] = list(args.option)
     if fan is not None:
         line["fanout"] = fan
         wf = ms_step + fan["fanout_ms"] + fan["gather_ms"]
