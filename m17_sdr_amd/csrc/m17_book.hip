@@ -73,7 +73,6 @@ __device__ __forceinline__ uint32_t crc_var_wave(const uint8_t *p, int L, const 
 
 struct alignas(16) LsfShared {
     uint16_t basis[240];
-    uint16_t crc[256];
     uint8_t  lsf[2][32];
     uint8_t  packet[800];
 };
@@ -82,9 +81,11 @@ struct alignas(16) LsfShared {
 __device__ __forceinline__ void lsf_shared_init(LsfShared &ls, const ChanState &cs, const uint16_t *crc_basis, int t, int nthreads)
 {
     for (int q = t; q < 240; q += nthreads) ls.basis[q] = crc_basis[q];
-    for (int q = t; q < 256; q += nthreads) ls.crc[q] = c_tab.crc[q];
     for (int q = t; q < 16; q += nthreads) reinterpret_cast<uint32_t *>(ls.lsf)[q] = reinterpret_cast<const uint32_t *>(cs.lsf)[q];
-    for (int q = t; q < 200; q += nthreads) reinterpret_cast<uint32_t *>(ls.packet)[q] = reinterpret_cast<const uint32_t *>(cs.packet)[q];
+    // m_packet: only its first 30 bytes are needed up front (decode_link_frame's CRC quirk, m17_rx_parse.cpp:98);
+    // the other 768 come in when the first packet frame of the call does (bookkeeping_wave), and the buffer goes
+    // back to the state only if a packet frame wrote to it -- stream traffic never touches it
+    for (int q = t; q < 8; q += nthreads) reinterpret_cast<uint32_t *>(ls.packet)[q] = reinterpret_cast<const uint32_t *>(cs.packet)[q];
 }
 
 // What m17_rx_parse does to file-static state, replayed over the channel's records in event
@@ -96,6 +97,7 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
     uint32_t g_errors = (uint32_t)uni((int)cs.g_errors), n_frames = (uint32_t)uni((int)cs.n_frames);
     uint32_t in_frame = (uint32_t)uni((int)cs.in_frame), epoch = (uint32_t)uni((int)cs.frame_id_epoch);
     int packet_idx = uni(cs.packet_idx);
+    bool packet_in = false;                                               // m_packet[32..800) loaded / buffer written to
     // m_lsf[0] / m_lsf[1] live one byte per lane in registers for the replay (lanes 0..29), and so do
     // the lane's eight CRC basis words: a LICH update and its CRC need no LDS round trip
     uint32_t b0 = (lane < 30) ? ls.lsf[0][lane] : 0u, b1 = (lane < 30) ? ls.lsf[1][lane] : 0u;
@@ -145,6 +147,12 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
                 const uint32_t d25 = ((uint32_t)__builtin_amdgcn_readlane((int)rd11, i) >> 8) & 0xFF;     // data[25]
                 const int eof = (int)(d25 >> 7), fnv = (int)((d25 >> 2) & 0x1F);
                 const uint8_t *dbytes = reinterpret_cast<const uint8_t *>(reinterpret_cast<const uint32_t *>(&rsrc[base + i]) + 5);
+                if (!packet_in) {                                           // wave-uniform: type comes from a readlane
+                    for (int q = 8 + lane; q < 200; q += 64)
+                        reinterpret_cast<uint32_t *>(ls.packet)[q] = reinterpret_cast<const uint32_t *>(cs.packet)[q];
+                    packet_in = true;
+                    group_sync();
+                }
                 if (eof) {
                     int cnt = fnv;
                     if (packet_idx + cnt > 800) cnt = 800 - packet_idx;
@@ -175,7 +183,8 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
     }
     group_sync();
     if (lane < 16) reinterpret_cast<uint32_t *>(cs.lsf)[lane] = reinterpret_cast<const uint32_t *>(ls.lsf)[lane];
-    for (int q = lane; q < 200; q += 64) reinterpret_cast<uint32_t *>(cs.packet)[q] = reinterpret_cast<const uint32_t *>(ls.packet)[q];
+    if (packet_in)
+        for (int q = lane; q < 200; q += 64) reinterpret_cast<uint32_t *>(cs.packet)[q] = reinterpret_cast<const uint32_t *>(ls.packet)[q];
 }
 
 
