@@ -87,21 +87,60 @@ __device__ __forceinline__ void emit_record_grp(m17gpu_rec_dev *recs, int rec_ca
 
 // rx_sync_filter (m17_rx_sync.cpp:25-31): matched and derivative filter as one packed (s, d)
 // chain, ascending order, bare first product.  xs = delay line at this instant, tp = 32 tap pairs.
+//
+// The 31 packed multiplies and 30 packed adds are written out with every product formed two instructions before
+// the add that consumes it.  Left to the compiler, half of the products were consumed by the very next instruction:
+// a packed multiply with op_sel needs a wait state before a dependent read on gfx950, so the schedule carried 20
+// s_nop and 16 separate LDS waits per round of 142 issue slots.  Same instructions, same order of the adds.
+//   P, Q alternate as the product in flight; X = (x[2q], x[2q+1]); T = (matched tap, derivative tap) of one sample.
+#define M17_FIR4(A, P, Q, X0, X1, T0, T1, T2, T3)                                             \
+    asm volatile("v_pk_mul_f32 %1, %3, %5 op_sel_hi:[0,1]\n\t"                                 \
+                 "v_pk_add_f32 %0, %0, %2\n\t"                                                 \
+                 "v_pk_mul_f32 %2, %3, %6 op_sel:[1,0]\n\t"                                    \
+                 "v_pk_add_f32 %0, %0, %1\n\t"                                                 \
+                 "v_pk_mul_f32 %1, %4, %7 op_sel_hi:[0,1]\n\t"                                 \
+                 "v_pk_add_f32 %0, %0, %2\n\t"                                                 \
+                 "v_pk_mul_f32 %2, %4, %8 op_sel:[1,0]\n\t"                                    \
+                 "v_pk_add_f32 %0, %0, %1"                                                      \
+                 : "+v"(A), "=&v"(P), "+v"(Q) : "v"(X0), "v"(X1), "v"(T0), "v"(T1), "v"(T2), "v"(T3))
 __device__ __forceinline__ v2f fir_pair(const float *xs, const float4 (&tp)[16])
 {
     // (the offset may be odd: plain float reads, the compiler pairs them into ds_read2_b32)
-    float2 xv[15];
+    v2f xv[16];
 #pragma unroll
-    for (int q = 0; q < 15; ++q) { xv[q].x = xs[2 * q]; xv[q].y = xs[2 * q + 1]; }
-    const float xl = xs[30];
-    v2f acc = (v2f){xv[0].x, xv[0].x} * (v2f){tp[0].x, tp[0].y};
-    acc = acc + (v2f){xv[0].y, xv[0].y} * (v2f){tp[0].z, tp[0].w};
-#pragma unroll
-    for (int q = 1; q < 15; ++q) {
-        acc = acc + (v2f){xv[q].x, xv[q].x} * (v2f){tp[q].x, tp[q].y};
-        acc = acc + (v2f){xv[q].y, xv[q].y} * (v2f){tp[q].z, tp[q].w};
-    }
-    return acc + (v2f){xl, xl} * (v2f){tp[15].x, tp[15].y};
+    for (int q = 0; q < 15; ++q) xv[q] = (v2f){xs[2 * q], xs[2 * q + 1]};
+    xv[15] = (v2f){xs[30], 0.0f};
+#define M17_TLO(q) ((v2f){tp[q].x, tp[q].y})
+#define M17_THI(q) ((v2f){tp[q].z, tp[q].w})
+    v2f acc, P, Q;
+    // samples 0..3: acc = p0 (bare), then + p1, + p2; p3 stays in flight
+    asm volatile("v_pk_mul_f32 %0, %3, %5 op_sel_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 %2, %3, %6 op_sel:[1,0]\n\t"
+                 "v_pk_mul_f32 %1, %4, %7 op_sel_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %0, %0, %2\n\t"
+                 "v_pk_mul_f32 %2, %4, %8 op_sel:[1,0]\n\t"
+                 "v_pk_add_f32 %0, %0, %1"
+                 : "=&v"(acc), "=&v"(P), "=&v"(Q)
+                 : "v"(xv[0]), "v"(xv[1]), "v"(M17_TLO(0)), "v"(M17_THI(0)), "v"(M17_TLO(1)), "v"(M17_THI(1)));
+    M17_FIR4(acc, P, Q, xv[2], xv[3], M17_TLO(2), M17_THI(2), M17_TLO(3), M17_THI(3));
+    M17_FIR4(acc, P, Q, xv[4], xv[5], M17_TLO(4), M17_THI(4), M17_TLO(5), M17_THI(5));
+    M17_FIR4(acc, P, Q, xv[6], xv[7], M17_TLO(6), M17_THI(6), M17_TLO(7), M17_THI(7));
+    M17_FIR4(acc, P, Q, xv[8], xv[9], M17_TLO(8), M17_THI(8), M17_TLO(9), M17_THI(9));
+    M17_FIR4(acc, P, Q, xv[10], xv[11], M17_TLO(10), M17_THI(10), M17_TLO(11), M17_THI(11));
+    M17_FIR4(acc, P, Q, xv[12], xv[13], M17_TLO(12), M17_THI(12), M17_TLO(13), M17_THI(13));
+    // samples 28, 29, 30 and the product still in flight
+    asm volatile("v_pk_mul_f32 %1, %3, %5 op_sel_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %0, %0, %2\n\t"
+                 "v_pk_mul_f32 %2, %3, %6 op_sel:[1,0]\n\t"
+                 "v_pk_add_f32 %0, %0, %1\n\t"
+                 "v_pk_mul_f32 %1, %4, %7 op_sel_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %0, %0, %2\n\t"
+                 "v_pk_add_f32 %0, %0, %1"
+                 : "+v"(acc), "=&v"(P), "+v"(Q)
+                 : "v"(xv[14]), "v"(xv[15]), "v"(M17_TLO(14)), "v"(M17_THI(14)), "v"(M17_TLO(15)));
+#undef M17_TLO
+#undef M17_THI
+    return acc;
 }
 
 // ---- lane-group primitives on DPP rows (a row is 16 lanes; LPC is 16, 32 or 64) -------------------
