@@ -10,10 +10,10 @@
 //                  lanes (2j) mod 4 and (2j+1) mod 4, so the eight old metrics arrive as
 //                  quad_perm operands of the eight adds -- no LDS crossbar (ds_bpermute) on
 //                  the per-step critical path, which is what bounds the 16-lane form
-//                  (viterbi16 in m17_kernels.hip).  Soft bits are produced 32 trellis steps
+//                  (viterbi16 in m17_kernels.hip).  Soft bits are produced 16 trellis steps
 //                  at a time straight from the frame symbols (demap . de-randomise .
-//                  de-interleave . de-puncture as one table gather), so a frame needs
-//                  1.5 KB of LDS and 16 frames fit a wave.
+//                  de-interleave . de-puncture as one table), so a frame needs 432 B of LDS
+//                  (stream; 624 B any type) and 16 frames fit a wave.
 //   (k_book_chan, the in-order per-channel bookkeeping, follows in m17_book.hip.)
 //
 // Branch metrics: metric[idx] = (idx&2 ? m1 : -m1) + (idx&1 ? m2 : -m2) (m17_conv.cpp:88-91).
@@ -26,13 +26,14 @@
 namespace m17dev {
 
 constexpr int DQ_FRAMES = 16;                  // frames per wave
-constexpr int DQ_CHUNK  = 32;                  // trellis steps per soft-bit chunk
+constexpr int DQ_CHUNK  = 16;                  // trellis steps per soft-bit chunk
+constexpr int DQ_NPER   = DQ_CHUNK / 2;        // soft bits per lane and chunk
 constexpr int DQ_RING   = 2 * DQ_CHUNK;
 constexpr int DQ_DECW   = 31;                  // ceil(244 / 8) decision rows: any frame type
 constexpr int DQ_DECW_STREAM = 19;             // ceil(148 / 8): stream frames
 
 // Per-frame LDS.  The record payload bytes are assembled after the forward pass, in the ring's place.
-// DECW = 31: 752 B = 4 x 47 dwords, DECW = 19: 560 B = 4 x 35 dwords -- either way the 16 frames of a wave
+// DECW = 31: 624 B = 4 x 39 dwords, DECW = 19: 432 B = 4 x 27 dwords -- either way the 16 frames of a wave
 // start 4 banks apart modulo 64, so the same field of all frames tiles the banks.
 template <int DECW>
 struct alignas(16) QuadFrameT {
@@ -43,7 +44,7 @@ struct alignas(16) QuadFrameT {
     };
     static constexpr int kDecw = DECW;
 };
-static_assert(sizeof(QuadFrameT<DQ_DECW>) == 752 && sizeof(QuadFrameT<DQ_DECW_STREAM>) == 560, "QuadFrame layout");
+static_assert(sizeof(QuadFrameT<DQ_DECW>) == 16 * DQ_DECW + 8 * DQ_CHUNK && sizeof(QuadFrameT<DQ_DECW_STREAM>) == 16 * DQ_DECW_STREAM + 8 * DQ_CHUNK, "QuadFrame layout");
 
 template <int CTRL> __device__ __forceinline__ float dppf(float v)
 {
@@ -136,7 +137,7 @@ void k_worklist(const m17gpu_rec_dev *__restrict__ recs, int rec_cap, const int3
 // table row and every loop bound live in SGPRs.  Quads whose frame has another type (plain-batch mode only; the work
 // lists are per type) ride along on their own symbols and write nothing.
 // The frame's 192 symbols stay in global memory (gs; written by the framer just before): every soft bit is one gather
-// through the table, the gathers of the NEXT 32 trellis steps fly while the current 32 are processed.  Everything a
+// through the table, the loads of the NEXT 16 trellis steps fly while the current 16 are processed.  Everything a
 // frame needs first -- the 8 sync symbols, the LICH symbols, the first chunk -- is requested in one go at the top, and
 // the two dependent Golay table reads ride under the forward pass, so a frame pays one memory round trip, not five.
 // Fences inside are wave-local LDS fences: a workgroup-scope fence would also drain the loads in flight.
@@ -161,9 +162,9 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW> &F, const floa
     float ncor;
     auto fetch_chunk = [&](int c0) {
         if constexpr (REGROUPED) {
-            const float4 *g4 = reinterpret_cast<const float4 *>(gs + 104 + 2 * c0 + 16 * j);
+            const float4 *g4 = reinterpret_cast<const float4 *>(gs + 104 + 2 * c0 + DQ_NPER * j);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float4 v = g4[r]; raw[4 * r] = v.x; raw[4 * r + 1] = v.y; raw[4 * r + 2] = v.z; raw[4 * r + 3] = v.w; }
+            for (int r = 0; r < DQ_NPER / 4; ++r) { const float4 v = g4[r]; raw[4 * r] = v.x; raw[4 * r + 1] = v.y; raw[4 * r + 2] = v.z; raw[4 * r + 3] = v.w; }
         } else {
 #pragma unroll
             for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) raw[r] = dq_symbol(gs, gt[(2 * c0 + j + 4 * r) & 511]);
@@ -171,12 +172,12 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW> &F, const floa
     };
     auto commit_chunk = [&](int c0) {
         if constexpr (REGROUPED) {
-            float v[16];
+            float v[DQ_NPER];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = dq_soft(gt[(2 * c0 + 16 * j + r) & 511], raw[r], ncor);
+            for (int r = 0; r < DQ_NPER; ++r) v[r] = dq_soft(gt[(2 * c0 + DQ_NPER * j + r) & 511], raw[r], ncor);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                reinterpret_cast<float4 *>(F.ring)[4 * j + r] = make_float4(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);
+            for (int r = 0; r < DQ_NPER / 4; ++r)
+                reinterpret_cast<float4 *>(F.ring)[(DQ_NPER / 4) * j + r] = make_float4(v[4 * r], v[4 * r + 1], v[4 * r + 2], v[4 * r + 3]);
         } else {
 #pragma unroll
             for (int r = 0; r < 2 * DQ_CHUNK / 4; ++r) F.ring[j + 4 * r] = dq_soft(gt[(2 * c0 + j + 4 * r) & 511], raw[r], ncor);
@@ -341,7 +342,7 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW> &F, const floa
 // ONLY == 0: any frame type, a table row per wave.
 template <int ONLY, int WAVES>
 struct alignas(16) DqShared {
-    QuadFrameT<(ONLY == 2) ? DQ_DECW_STREAM : DQ_DECW> fr[WAVES][DQ_FRAMES];   // 8.75 KB (stream) / 11.75 KB per wave
+    QuadFrameT<(ONLY == 2) ? DQ_DECW_STREAM : DQ_DECW> fr[WAVES][DQ_FRAMES];   // 6.75 KB (stream) / 9.75 KB per wave
     uint32_t gt_rows[ONLY ? 1 : WAVES][512];                                   // DevTables.gather row of the current type, re-coded
     DqLich   lich_row[96];
 };
@@ -483,7 +484,7 @@ void k_decode_quad(const float *__restrict__ fsym, const int32_t *__restrict__ w
 // launch of its own, behind the stream launch, that was 38 us added to every call; here it runs beside the stream
 // tasks.  The any-type workgroups come first so that they are placed at once; with their lists empty they leave
 // before touching their tables.
-__global__ __launch_bounds__(256, 4)
+__global__ __launch_bounds__(256, 5)
 void k_decode_lists(const float *__restrict__ fsym, const int32_t *__restrict__ work,
                     const int32_t *__restrict__ nwork, int cap, m17gpu_rec_dev *__restrict__ recs,
                     const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr, int slot_floats, int n_other)

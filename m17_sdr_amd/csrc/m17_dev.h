@@ -12,7 +12,7 @@ constexpr int kFrameSyms    = 192;    // m17defines.h:66
 // frame is stored in the order its decoder reads it (DevTables.regroup), so that the decoder's loads are contiguous --
 // gathered from the plain 192 symbols, every soft bit cost an L2 round trip of a whole cache line:
 //   [0,8) sync symbols; [8,104) the source symbols of the 96 LICH soft bits; [104,400) those of the 296 de-punctured
-//   payload soft bits (an erasure's place holds some symbol, never used); [400,424) not written (the last 32-step
+//   payload soft bits (an erasure's place holds some symbol, never used); [400,424) not written (the last
 //   chunk reads it and masks it out).
 constexpr int kSlotFloats   = 424;
 constexpr int kRegroup      = 392;

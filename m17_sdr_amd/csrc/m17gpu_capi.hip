@@ -212,13 +212,13 @@ int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_c
     const long long slots = (long long)cn * rec_cap;
     hipLaunchKernelGGL(k_worklist, dim3(cdiv(slots, 1024)), dim3(1024), 0, st, recs, rec_cap, cnt, cn,
                        work, nwork, (int)slots);
-    // one launch for all three lists (k_decode_lists): stream frames, the bulk of any traffic, on four workgroups of
-    // four waves per CU; link-setup and packet frames on up to 512 leading workgroups
+    // one launch for all three lists (k_decode_lists): stream frames, the bulk of any traffic, on five workgroups of
+    // four waves per CU (30.5 KB of LDS and 96 VGPRs each); link-setup and packet frames on up to 512 leading workgroups
     const int tasks = cdiv(slots, DQ_FRAMES) + 2;
     int n_other = cdiv(tasks, 2);
     if (n_other > 512) n_other = 512;
     int grid = cdiv(tasks, 4);
-    if (grid > 256 * 4) grid = 256 * 4;
+    if (grid > 256 * 5) grid = 256 * 5;
     hipLaunchKernelGGL(k_decode_lists, dim3(grid + n_other), dim3(256), 0, st, fsym, work, nwork, (int)slots, recs,
                        ctx->d_genc, ctx->d_gerr, kSlotFloats, n_other);
     HIPCHK(hipGetLastError());
