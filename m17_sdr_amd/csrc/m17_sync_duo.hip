@@ -101,6 +101,8 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
             }
         }
         wave_fence();
+        float4 tp[16];                                                // 32 tap pairs of the current branch, kept across blocks
+        int tap_index = -1;
         for (int b = b0; b < bend; ++b) {
             // next block's input: loads issued now, committed at the end of the block
             constexpr int PF = kDiscOut / LPC;
@@ -119,8 +121,6 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                 // ---- timing recovery in rounds of 64 instants; x[i .. i+30] is the delay line at input i
                 const int thresh = lockv ? 80 : 10;
                 int p = 0, m_idx = 0;
-                float4 tp[16];                                        // 32 tap pairs of the current branch
-                int tap_index = -1;
                 while (p < kDiscOut) {
                     if (clk == 1) {
                         // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72)
@@ -159,10 +159,11 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                     const int naccept = cr ? kl + 1 : nv;
                     if (gl < naccept && (m_idx + gl) >= 0) my.H[(hp + m_idx + gl) & (kDuoRing - 1)] = s;
                     m_idx += naccept;
-                    sum = __shfl(s, naccept - 1, 64);
-                    dif = __shfl(d, naccept - 1, 64);
+                    // (wave-uniform lane numbers: v_readlane, not the LDS crossbar of a shuffle)
+                    sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), uni(naccept - 1)));
+                    dif = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), uni(naccept - 1)));
                     if (cr) {
-                        const int ts = __shfl(tk, kl, 64);
+                        const int ts = __builtin_amdgcn_readlane(tk, uni(kl));
                         thr = 0; clk = 0;
                         if (ts > thresh) {
                             index = (index + 1 == kPhases) ? 0 : index + 1;
