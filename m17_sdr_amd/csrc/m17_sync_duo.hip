@@ -37,6 +37,14 @@ typedef __attribute__((address_space(3))) volatile int lds_vint;
 __device__ __forceinline__ int lds_peek(const int *p) { return *(const lds_vint *)p; }
 __device__ __forceinline__ void lds_poke(int *p, int v) { *(lds_vint *)p = v; }
 
+// the same wait with an LDS-only acquire, for a waiter that reads only LDS behind the flag and has global loads in
+// flight (the timing wave's prefetch): a full workgroup-scope fence would also drain vmcnt
+template <int SLEEP = 1>
+__device__ __forceinline__ void duo_wait_lds(const int *flag, int need)
+{
+    while (lds_peek(flag) < need) __builtin_amdgcn_s_sleep(SLEEP);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 template <int SLEEP = 1>
 __device__ __forceinline__ void duo_wait(const int *flag, int need)
 {
@@ -48,6 +56,13 @@ __device__ __forceinline__ void duo_wait(const int *flag, int need)
 __device__ __forceinline__ void duo_post(int *flag, int value, int lane)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) lds_poke(flag, value);
+}
+
+// publish with an LDS-only release: everything the reader takes from this wave is in LDS
+__device__ __forceinline__ void duo_post_lds(int *flag, int value, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) lds_poke(flag, value);
 }
 
@@ -185,7 +200,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                 int actual = known_lock;
                 STAMP(0);
                 if (b > b0) {
-                    duo_wait(frm_blk, b - b0);
+                    duo_wait_lds(frm_blk, b - b0);
                     STAMP(1);
                     actual = lds_peek(&my.lock_after[(b - 1) & 3]);
                 }
@@ -195,7 +210,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
             }
             known_lock = lockv;
             if (gl == 0) my.nsym[b & 3] = n;
-            duo_post(tim_blk, b - b0 + 1, gl);
+            duo_post_lds(tim_blk, b - b0 + 1, gl);
             hp += n;
             // delay line: last 30 inputs; then the prefetched block moves in
             {
