@@ -167,6 +167,18 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// z[0], z[1] of dsp_arctan_disc2 (m17_dsp.cpp:196,205-206) after the last block of the call of the channel whose
+// block 0 is item cb: the limited last two samples of the channel's nblk blocks
+__device__ __forceinline__ void fe_next_z(const uint4 *iq, int cb, int nblk, float &z0re, float &z0im, float &z1re, float &z1im)
+{
+    const uint32_t *pe = reinterpret_cast<const uint32_t *>(iq) + (size_t)(cb + nblk) * kBlockSamples;
+    const uint32_t a = pe[-2], b = pe[-1];
+    z1re = s16_to_float((int)(short)(a & 0xFFFF)); z1im = s16_to_float((int)a >> 16);
+    z0re = s16_to_float((int)(short)(b & 0xFFFF)); z0im = s16_to_float((int)b >> 16);
+    limit(z1re, z1im);
+    limit(z0re, z0im);
+}
+
 __global__ __launch_bounds__(64 * FE_WAVES)
 void k_frontend(const uint4 *__restrict__ iq,        // [total][480] uint4 (4 IQ samples each)
                 ChanState *__restrict__ st,
@@ -186,9 +198,15 @@ void k_frontend(const uint4 *__restrict__ iq,        // [total][480] uint4 (4 IQ
     // discriminator memory z[0], z[1] (m17_dsp.cpp:196): from channel state for
     // the first block of the call, otherwise the limited last two samples of the
     // preceding block, which sit right in front of this row in the IQ array.
+    // The state for the NEXT call -- the limited last two samples of the channel's last block -- is written by this
+    // same lane of block 0, behind its own read (fe_next_z): written by the lane of the last block, as it used to be,
+    // it could land before the block-0 lane of another wave had read the old one (workgroups of different XCDs run
+    // far apart in a large grid; seen as run-to-run differences above 65,536 channels).
     float z0re, z0im, z1re, z1im;
+    float n0re = 0.0f, n0im = 0.0f, n1re = 0.0f, n1im = 0.0f;
     if (blk == 0) {
         z0re = st[chan].z0re; z0im = st[chan].z0im; z1re = st[chan].z1re; z1im = st[chan].z1im;
+        fe_next_z(iq, cb, nblk, n0re, n0im, n1re, n1im);
     } else {
         const uint32_t *p = reinterpret_cast<const uint32_t *>(iq) + (size_t)cb * kBlockSamples;
         const uint32_t a = p[-2], b = p[-1];
@@ -256,8 +274,8 @@ void k_frontend(const uint4 *__restrict__ iq,        // [total][480] uint4 (4 IQ
     }
     if (valid) {
         offs[cb] = offset / (float)kBlockSamples;     // offset/len (m17_dsp.cpp:213)
-        if (update_state && blk == nblk - 1) {
-            st[chan].z0re = z0re; st[chan].z0im = z0im; st[chan].z1re = z1re; st[chan].z1im = z1im;
+        if (update_state && blk == 0) {
+            st[chan].z0re = n0re; st[chan].z0im = n0im; st[chan].z1re = n1re; st[chan].z1im = n1im;
         }
     }
 }
@@ -310,9 +328,9 @@ __device__ __forceinline__ void fq_sum_chunk(const float *row, float &offset, fl
 __global__ __launch_bounds__(64 * FQ_WAVES)
 void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
                   float *__restrict__ disc_raw, float *__restrict__ offs,
-                  int nblk, int total, int update_state, int b0, int cbk)
+                  int nblk, int total, int update_state)
 {
-    // this launch covers blocks b0 .. b0+cbk-1 of every channel: total = C * cbk items
+    // total = C * nblk items, channel-major
     __shared__ __attribute__((aligned(16))) uint32_t tile[FQ_WAVES][16 * FQ_STRIDE];  // raw IQ, then u*0.5
     __shared__ __attribute__((aligned(16))) float otile[FQ_WAVES][16 * FQ_STRIDE];    // 64 picked outputs per row
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
@@ -327,9 +345,12 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
     float *myo = otile[wave];
 
     // z[0], z[1] at the start of the block, identical in the four lanes of a quad
+    // (the next call's state is written by the quad of block 0 itself, behind its read: see k_frontend)
     float c0re, c0im, c1re, c1im;
+    float n0re = 0.0f, n0im = 0.0f, n1re = 0.0f, n1im = 0.0f;
     if (blk == 0) {
         c0re = st[chan].z0re; c0im = st[chan].z0im; c1re = st[chan].z1re; c1im = st[chan].z1im;
+        fe_next_z(iq, cb, nblk, n0re, n0im, n1re, n1im);
     } else {
         const uint32_t *p = reinterpret_cast<const uint32_t *>(iq) + (size_t)cb * kBlockSamples;
         const uint32_t a = p[-2], b = p[-1];
@@ -429,8 +450,8 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
     }
     if (sub == 0 && valid) {
         offs[cb] = offset / (float)kBlockSamples;
-        if (update_state && blk == nblk - 1) {
-            st[chan].z0re = c0re; st[chan].z0im = c0im; st[chan].z1re = c1re; st[chan].z1im = c1im;
+        if (update_state && blk == 0) {
+            st[chan].z0re = n0re; st[chan].z0im = n0im; st[chan].z1re = n1re; st[chan].z1im = n1im;
         }
     }
 }

@@ -142,11 +142,10 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // Channel range [c0, c0 + cn) of the context (cn < 0: all): every array of the path is channel-major, so a range
 // is the same launch on offset pointers.
 int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc, float *offs,
-                    int update_state, hipStream_t st, int b0 = 0, int cbk = -1, int c0 = 0, int cn = -1)
+                    int update_state, hipStream_t st, int c0 = 0, int cn = -1)
 {
-    if (cbk < 0) cbk = nblk;
     if (cn < 0) cn = ctx->C;
-    const int total = cn * cbk;
+    const int total = cn * nblk;
     d_iq += (size_t)c0 * nblk * kBlockSamples * 2;
     disc += (size_t)c0 * nblk * kDiscOut;
     offs += (size_t)c0 * nblk;
@@ -156,7 +155,7 @@ int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc,
     const bool quad = ctx->fe_impl != 1;
     if (quad)
         hipLaunchKernelGGL(k_frontend_q, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st,
-                           reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state, b0, cbk);
+                           reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state);
     else
         hipLaunchKernelGGL(k_frontend, dim3(cdiv(total, 64 * FE_WAVES)), dim3(64 * FE_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state);

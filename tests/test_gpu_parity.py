@@ -252,6 +252,37 @@ def test_config4_16384_channels_awgn_bit_exact(ebn0):
     rx.close()
 
 
+def test_config5_total_channel_count_on_one_gpu_bit_exact():
+    """BASELINE configs[4] is 131,072 channels over 8 GPUs; the same channel count in ONE context (6 blocks, 6 GB of
+    IQ) checks every index computation of the chain at eight times the per-GPU size: work-list slots, frame-slot and
+    symbol-stream offsets, launch grids.  All channels against the oracle, records and end state."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    C, nblk = 131072, 6
+    rx = m.Receiver(C, nblk)
+    sig = rx.gen_batch(nblk, n_stream_frames=6, ebn0_db=12.0, noise_cutoff_hz=6250.0)
+    out = rx.rx_blocks(sig["iq"], 1, rx.alloc_outputs(nblk))
+    torch.cuda.synchronize()
+    iq = sig["iq"].cpu().numpy()
+    del sig
+    och = oracle.Channels(C)
+    ref = och.rx_blocks(iq, mode=1, nthreads=16, want_syms=False)
+    counts = out["counts"].cpu().numpy()
+    np.testing.assert_array_equal(counts, ref["counts"])
+    recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
+    cap = recs.shape[1]
+    valid = np.arange(cap)[None, :] < counts[:, None]
+    g = recs.view(np.uint8).reshape(C, cap, 64)[valid]
+    r = ref["recs"].view(np.uint8).reshape(C, cap, 64)[valid]
+    bad = np.nonzero((g != r).any(axis=1))[0]
+    assert bad.size == 0, (bad[:5], g[bad[:1]], r[bad[:1]])
+    np.testing.assert_array_equal(rx.lock(), (och.field("m_flock") != 0).astype(np.uint8))
+    np.testing.assert_array_equal(rx.lsf(), och.field("m_lsf"))
+    np.testing.assert_array_equal(rx.counters(), och.field("counters"))
+    assert int(((recs["flags"][valid] & m.F_PARSED) != 0).sum()) > 20000
+    rx.close()
+
+
 def test_large_batch_split_call_property():
     """Size-independent property at a large channel count: one call over 2n blocks equals two
     calls over n blocks each (records, symbols and state), on the GPU alone."""
