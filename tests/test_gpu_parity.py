@@ -283,6 +283,41 @@ def test_config5_total_channel_count_on_one_gpu_bit_exact():
     rx.close()
 
 
+@pytest.mark.parametrize("C,nblk", [(1024, 120), (2500, 60), (5003, 30)])
+def test_long_calls_and_ragged_counts_bit_exact(C, nblk):
+    """Many blocks per call (4.8 s of signal in one launch: the symbol ring of the two-wave kernel wraps several
+    times, record capacity 2*nblk+2 is used in full) and channel counts that are no multiple of the channels per wave
+    or workgroup of the kernel the size selects (two-wave kernel, 32 and 16 lanes per channel).  Band-limited AWGN
+    at 9 dB so that locks are lost and regained inside the call.  Everything against the oracle."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    rx = m.Receiver(C, nblk)
+    sig = rx.gen_batch(nblk, n_stream_frames=18, ebn0_db=9.0, noise_cutoff_hz=6250.0)
+    out = rx.rx_blocks(sig["iq"], 1, rx.alloc_outputs(nblk, want_syms=True))
+    torch.cuda.synchronize()
+    iq = sig["iq"].cpu().numpy()
+    och = oracle.Channels(C)
+    ref = och.rx_blocks(iq, mode=1, nthreads=16)
+    counts = out["counts"].cpu().numpy()
+    np.testing.assert_array_equal(counts, ref["counts"])
+    np.testing.assert_array_equal(out["nsyms"].cpu().numpy(), ref["nsyms"])
+    np.testing.assert_array_equal(out["syms"].cpu().numpy().view(np.uint32), ref["syms"].view(np.uint32))
+    recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
+    cap = recs.shape[1]
+    valid = np.arange(cap)[None, :] < counts[:, None]
+    g = recs.view(np.uint8).reshape(C, cap, 64)[valid]
+    r = ref["recs"].view(np.uint8).reshape(C, cap, 64)[valid]
+    bad = np.nonzero((g != r).any(axis=1))[0]
+    assert bad.size == 0, (bad[:5], g[bad[:1]], r[bad[:1]])
+    np.testing.assert_array_equal(rx.lock(), (och.field("m_flock") != 0).astype(np.uint8))
+    np.testing.assert_array_equal(rx.lsf(), och.field("m_lsf"))
+    np.testing.assert_array_equal(rx.counters(), och.field("counters"))
+    assert int((recs["flags"][valid] & m.F_AOS != 0).sum()) > C // 8          # locks were taken ...
+    if nblk >= 60:
+        assert int((recs["flags"][valid] & (m.F_LOST | m.F_EOT) != 0).sum()) > 0   # ... and given up inside the call
+    rx.close()
+
+
 def test_large_batch_split_call_property():
     """Size-independent property at a large channel count: one call over 2n blocks equals two
     calls over n blocks each (records, symbols and state), on the GPU alone."""
