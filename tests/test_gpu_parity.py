@@ -318,6 +318,41 @@ def test_long_calls_and_ragged_counts_bit_exact(C, nblk):
     rx.close()
 
 
+def test_config4_state_across_calls_at_full_size():
+    """The bench feeds 16,384 channels one continuous stream cut into calls: three consecutive 8-block calls on one
+    context against the oracle fed the same way -- every state the chain carries from call to call (discriminator
+    memory, delay line, timing loop, partial frame, LICH assembly, counters) at the size the bench runs."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    C, nblk, calls = 16384, 8, 3
+    rx = m.Receiver(C, nblk)
+    sig = rx.gen_batch(nblk * calls, n_stream_frames=30, ebn0_db=10.0, noise_cutoff_hz=6250.0)
+    iq_all = sig["iq"]
+    iq_host = iq_all.cpu().numpy()
+    och = oracle.Channels(C)
+    for k in range(calls):
+        part = iq_all[:, k * nblk:(k + 1) * nblk].contiguous()
+        out = rx.rx_blocks(part, 1, rx.alloc_outputs(nblk, want_syms=True))
+        torch.cuda.synchronize()
+        ref = och.rx_blocks(np.ascontiguousarray(iq_host[:, k * nblk:(k + 1) * nblk]), mode=1, nthreads=16)
+        counts = out["counts"].cpu().numpy()
+        np.testing.assert_array_equal(counts, ref["counts"])
+        np.testing.assert_array_equal(out["nsyms"].cpu().numpy(), ref["nsyms"])
+        np.testing.assert_array_equal(out["syms"].cpu().numpy().view(np.uint32), ref["syms"].view(np.uint32))
+        recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
+        cap = recs.shape[1]
+        valid = np.arange(cap)[None, :] < counts[:, None]
+        g = recs.view(np.uint8).reshape(C, cap, 64)[valid]
+        r = ref["recs"].view(np.uint8).reshape(C, cap, 64)[valid]
+        bad = np.nonzero((g != r).any(axis=1))[0]
+        assert bad.size == 0, (k, bad[:5], g[bad[:1]], r[bad[:1]])
+        np.testing.assert_array_equal(rx.lsf(), och.field("m_lsf"))
+        np.testing.assert_array_equal(rx.counters(), och.field("counters"))
+    delivered = int(((recs["flags"][valid] & m.F_DELIVERED) != 0).sum())
+    assert delivered > 10000, delivered                # by the third call LICH assembly is complete on most channels
+    rx.close()
+
+
 def test_large_batch_split_call_property():
     """Size-independent property at a large channel count: one call over 2n blocks equals two
     calls over n blocks each (records, symbols and state), on the GPU alone."""
