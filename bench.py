@@ -321,7 +321,11 @@ def run_rank(args):
 
     fan = None
     if world > 1 and not args.no_fanout:
-        fan = fanout_legs(args, torch, dist, rx, out, iq[args.warmup % len(iq)], world, rank, backend, C, nblk, mode)
+        # after the timed region and outside `value`: a failure of the transfer legs must not cost the measurement
+        try:
+            fan = fanout_legs(args, torch, dist, rx, out, iq[args.warmup % len(iq)], world, rank, backend, C, nblk, mode)
+        except Exception as e:                                   # noqa: BLE001 -- reported in the line
+            fan = {"fanout_error": f"{type(e).__name__}: {e}"[:300]}
 
     syms = world * C * nblk * 192 * args.steps
     msym = syms / dt / 1e6
