@@ -1,0 +1,356 @@
+// m17_sync_wave.hip -- k_sync_frame_wave: timing recovery + sync correlator + framer, ONE WAVE PER
+// CHANNEL with the whole control flow on the scalar unit and the filter taps in SGPRs.
+//
+// Reference: m17_rx_sync_samples (m17_rx_sync.cpp:77-99), m17_rx_sym (m17_rx_frame.cpp:126-177).
+//
+// Why (round-2 measurements): the lane-group kernel (four channels per wave, 16
+// lanes each, taps in 62 VGPRs) ran at two waves per SIMD -- 241 VGPRs, 63 KB of LDS per workgroup --
+// and at one instruction per ~9 cycles per wave: bound by latency, not by its 890 instructions per
+// channel-block.  Its control variables are equal within a lane group but differ between the groups of
+// a wave, so every branch is EXEC-mask divergence and every wave executes the union of its four
+// channels' paths.  Here a wave owns one channel:
+//   * every control variable (m_clk, m_thr, m_index, the symbol count, lock, frame clock) is
+//     wave-uniform: SGPRs, scalar ALU, scalar branches; vote masks come straight out of v_cmp;
+//   * the 31 (matched, derivative) tap pairs of the current polyphase branch are 62 SGPRs, loaded
+//     with s_load from the constant table when the branch changes, and are the scalar operand of the
+//     packed multiplies: no tap VGPRs, no tap LDS;
+//   * what is left per lane is the 31-sample window and the accumulators: ~70 VGPRs and 3.7 KB of LDS
+//     per wave, i.e. 6-7 waves per SIMD, which is what hides the LDS and issue latency.
+// A round takes 64 consecutive symbol instants under the current branch; a threshold crossing ends
+// the round early and the next round starts behind it (nothing past a crossing is ever used).
+// Symbols go into a per-channel LDS ring in which frames and hunt windows are read in place.
+#pragma clang fp contract(off)
+
+namespace m17dev {
+
+constexpr int kWvRing = 512;                   // 191 (frame in progress) + 193 (block being written) < 512
+
+struct WvChan {                                // LDS of one channel
+    float x[kTaps - 1 + kDiscOut + 2];         // delay-line history (30) + this block's 384 inputs
+    float H[kWvRing];                          // symbol ring
+};
+
+// The current branch's 31 (matched, derivative) tap pairs live in s[40:101] for the whole kernel: the kernel is compiled
+// with amdgpu_num_sgpr(46), which keeps the register allocator below s40, and only the two asm blocks below touch the
+// range (left to the allocator, 31 live 64-bit scalars plus the control state overflowed the 102 SGPRs and were
+// spilled to VGPR lanes around every round: 218 spills).  Tap pair j is s[40+2j : 41+2j].
+#define M17_TAP_CLOBBERS "s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s50","s51","s52","s53","s54","s55", \
+    "s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s68","s69","s70","s71","s72","s73","s74",   \
+    "s75","s76","s77","s78","s79","s80","s81","s82","s83","s84","s85","s86","s87","s88","s89","s90","s91","s92","s93",   \
+    "s94","s95","s96","s97","s98","s99","s100","s101"
+// 62 dwords of one row of DevTables.tap_pairs by scalar loads, waited for here: a branch change happens once per ~80
+// symbol instants at most, and the filter keeps the compiler's counted waits on its window reads
+__device__ __forceinline__ void load_taps_s(const float *row)
+{
+    asm volatile("s_load_dwordx16 s[40:55], %0, 0x0\n\t"
+                 "s_load_dwordx16 s[56:71], %0, 0x40\n\t"
+                 "s_load_dwordx16 s[72:87], %0, 0x80\n\t"
+                 "s_load_dwordx8 s[88:95], %0, 0xc0\n\t"
+                 "s_load_dwordx4 s[96:99], %0, 0xe0\n\t"
+                 "s_load_dwordx2 s[100:101], %0, 0xf0\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 :: "s"(row) : "memory", M17_TAP_CLOBBERS);
+}
+
+// rx_sync_filter (m17_rx_sync.cpp:25-31) for both filters as one packed (s, d) chain, ascending order, bare first
+// product, separate multiply and add, the tap pair as the scalar source operand of v_pk_mul_f32.  The whole round --
+// sixteen aligned 8-byte window reads, counted waits, 31 multiplies and 30 adds -- is ONE asm statement (text in
+// m17_fir_sgpr.inc, written by scripts/gen_fir_asm.py), so no compiler-visible register ever holds a window value
+// that is still in flight.  ds_read_b64 with lane stride 8 bytes covers 64 consecutive dwords per half-wave:
+// conflict-free, 2 LDS cycles each; the ds_read2_b32 form of the first version (lane stride 2 dwords, 32 banks:
+// 2-way conflicts, 8 cycles each) made the LDS pipe the limit of the kernel (~600 of its cycles per channel-block).
+//   lds_pair : LDS byte address of the aligned pair that holds the window's first sample (x[w & ~1])
+//   odd      : the window starts on the pair's second element (wave-uniform)
+#include "m17_fir_sgpr.inc"
+#define M17_FIR_OPERANDS                                                                                                 \
+    [acc] "=&v"(acc), [p] "=&v"(P), [q] "=&v"(Q), [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3),        \
+    [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6), [x7] "=&v"(x7), [x8] "=&v"(x8), [x9] "=&v"(x9), [x10] "=&v"(x10),   \
+    [x11] "=&v"(x11), [x12] "=&v"(x12), [x13] "=&v"(x13), [x14] "=&v"(x14), [x15] "=&v"(x15)
+__device__ __forceinline__ v2f fir_window_s(unsigned lds_pair, bool odd)
+{
+    v2f acc, P, Q, x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
+    if (!odd) asm volatile(M17_FIR_SGPR_EVEN : M17_FIR_OPERANDS : [a] "v"(lds_pair) : "memory");
+    else      asm volatile(M17_FIR_SGPR_ODD : M17_FIR_OPERANDS : [a] "v"(lds_pair) : "memory");
+    return acc;
+}
+typedef const __attribute__((address_space(3))) float *lds_cfp;
+
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+constexpr int WV_WAVES = 4;                    // channels (waves) per workgroup; the waves never synchronise
+
+__global__ __launch_bounds__(64 * WV_WAVES) __attribute__((amdgpu_num_sgpr(46)))
+void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
+                       const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
+                       ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
+                       m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
+                       float *__restrict__ syms, int32_t *__restrict__ nsyms,
+                       float *__restrict__ fsym, int b0, int bcount)
+{
+    constexpr int LPC = 64;
+    constexpr int RM = kWvRing - 1;
+    __shared__ __attribute__((aligned(16))) WvChan chs[WV_WAVES];
+    const int wave = uni((int)(threadIdx.x >> 6)), gl = lane_id();
+    const int chan = (int)blockIdx.x * WV_WAVES + wave;
+    if (chan >= C) return;
+    WvChan &my = chs[wave];
+    ChanState &cs = st[chan];
+    m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
+    if (!recs) rec_cap = 0;
+
+    // wave-uniform control state: scalar registers
+    int clk = uni(cs.clk), thr = uni(cs.thr), index = uni(cs.index);
+    float sum = unif(cs.sum), dif = unif(cs.dif);
+    int flock = uni(cs.flock), fclk = uni(cs.fclk), ferr = uni(cs.ferr);
+    uint32_t block_count = (uint32_t)uni((int)cs.block_count);
+    int nrec = (b0 == 0) ? 0 : uni(counts[chan]);
+    int sym_total = (b0 == 0) ? 0 : uni(cs.sym_total);
+    int hp = 256;                                           // ring position of the block's first symbol
+    RegroupLane<LPC> rg;
+    rg.load(gl);
+
+    if (gl < kTaps - 1) my.x[gl] = cs.buff[gl + 1];
+    // m_f_sym[0 .. fclk) is the frame in progress: ring [hp - fclk, hp); m_sync is the last 8 symbols
+    if (flock) { for (int q = gl; q < fclk; q += LPC) my.H[(hp - fclk + q) & RM] = cs.fsym[q]; }
+    else if (gl < 8) my.H[(hp - 8 + gl) & RM] = cs.sync[gl];
+    const float *dsrc = disc + (size_t)chan * nblk * kDiscOut;
+    const float *osrc = offs ? offs + (size_t)chan * nblk : nullptr;
+    {
+        const float off = osrc ? osrc[b0] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < kDiscOut / LPC; ++r) {
+            float v = __builtin_nontemporal_load(&dsrc[(size_t)b0 * kDiscOut + gl + LPC * r]);
+            if (osrc) v = v - off;                               // out[i] - offset (m17_dsp.cpp:217-219)
+            my.x[kTaps - 1 + gl + LPC * r] = v;
+        }
+    }
+    float *sym_out = syms ? syms + (size_t)chan * M17_SYM_STRIDE(nblk) + sym_total : nullptr;
+    wave_fence();
+
+    int tap_index = -1;                                      // the branch whose tap pairs are in s[40:101]
+    const int bend = b0 + bcount;
+#ifdef M17_STAMPS
+    // phase accumulators in LDS (the scalar registers are spoken for): lane 0 adds the ticks since the last stamp
+    __shared__ unsigned wstamps[WV_WAVES][12];
+    if (gl < 12) wstamps[wave][gl] = 0;
+    unsigned last_ = (unsigned)__builtin_amdgcn_s_memtime();
+#define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0); if (gl == 0) wstamps[wave][i] += now_ - last_; last_ = now_; } while (0)
+#define WCNT(i) do { if (gl == 0) wstamps[wave][i] += 1; } while (0)
+#else
+#define WSTAMP(i) do {} while (0)
+#define WCNT(i) do {} while (0)
+#endif
+    for (int b = b0; b < bend; ++b) {
+        WSTAMP(5);
+        // next block's input: loads issued now, committed at the end of the block
+        constexpr int PF = kDiscOut / LPC;
+        float pf[PF];
+        float noff = 0.0f;
+        if (b + 1 < bend) {
+            const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
+            noff = osrc ? osrc[b + 1] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < PF; ++r) pf[r] = __builtin_nontemporal_load(&nx[gl + LPC * r]);   // read once
+        }
+
+        // ---- timing recovery in rounds of 64 instants; x[i .. i+30] is the delay line at input i
+        const int lockv = (ext_lock >= 0) ? ext_lock : flock;        // m17_rx_lock(): the framer's state after the previous block
+        const int thresh = lockv ? 80 : 10;
+        int p = 0, m_idx = 0;
+        while (p < kDiscOut) {
+            if (clk == 1) {
+                // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72)
+                clk = 0;
+                const float d0 = (sum < 0.0f) ? -dif : dif;
+                if (d0 > 0.0f) thr++;
+                if (d0 < 0.0f) thr--;
+                if (thr > thresh) {
+                    index = (index + 1 == kPhases) ? 0 : index + 1; thr = 0;
+                    if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.H[(hp + m_idx) & RM] = 0.0f; m_idx++; }
+                }
+                if (thr < -thresh) {
+                    thr = 0; index = (index == 0) ? kPhases - 1 : index - 1;
+                    if (index == kPhases - 1) { clk = 1; m_idx--; }
+                }
+                p++;
+                WSTAMP(0);
+                continue;
+            }
+            WCNT(8);
+            if (tap_index != index) {
+                load_taps_s(&c_tab.tap_pairs[index][0]);
+                tap_index = index;
+                WCNT(9);
+            }
+            WSTAMP(0);
+            const int rem = (kDiscOut - p + 1) >> 1;          // filter instants left in the block
+            const int nv = rem < LPC ? rem : LPC;
+            const unsigned xa = (unsigned)(uintptr_t)(lds_cfp)(my.x + (p & ~1) + 2 * (gl < nv ? gl : 0));
+            const v2f a = fir_window_s(xa, (p & 1) != 0);
+            WSTAMP(1);
+            const float s = a.x, d = a.y;
+            const bool vote_ok = (gl < nv) && (p + 2 * gl + 1 < kDiscOut);
+            const float dd = (s < 0.0f) ? -d : d;             // sync_update, m17_rx_sync.cpp:38-42
+            const bool up = vote_ok && dd > 0.0f, dn = vote_ok && dd < 0.0f;
+            const unsigned long long um = __builtin_amdgcn_ballot_w64(up);
+            const unsigned long long dm = __builtin_amdgcn_ballot_w64(dn);
+            const int nu = (int)__popcll(um), nd = (int)__popcll(dm);
+            int naccept = nv, kl = -1, ts_ = 0;
+            if (thr + nu > thresh || thr - nd < -thresh) {
+                // a crossing is possible in this round: the counter after every tick, first crossing wins
+                const int pu = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+                const int pd = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0u));
+                const int tk = thr + pu - pd + (int)up - (int)dn;
+                const unsigned long long cr = __builtin_amdgcn_ballot_w64(vote_ok && (tk > thresh || tk < -thresh));
+                if (cr) {
+                    kl = (int)__builtin_ctzll(cr);
+                    naccept = kl + 1;
+                    ts_ = __builtin_amdgcn_readlane(tk, kl);
+                }
+            }
+            if (gl < naccept && (m_idx + gl) >= 0) my.H[(hp + m_idx + gl) & RM] = s;
+            m_idx += naccept;
+            sum = readlane_f(s, naccept - 1);
+            dif = readlane_f(d, naccept - 1);
+            if (kl >= 0) {
+                thr = 0; clk = 0;
+                if (ts_ > thresh) {
+                    index = (index + 1 == kPhases) ? 0 : index + 1;
+                    if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.H[(hp + m_idx) & RM] = 0.0f; m_idx++; }
+                } else {
+                    index = (index == 0) ? kPhases - 1 : index - 1;
+                    if (index == kPhases - 1) { clk = 1; m_idx--; }
+                }
+                p = p + 2 * kl + 2;
+            } else {
+                thr += nu - nd;
+                const int ilast = p + 2 * (nv - 1);
+                if (ilast + 1 < kDiscOut) { clk = 0; p = ilast + 2; }
+                else { clk = 1; p = kDiscOut; }                     // the last vote tick falls into the next block
+            }
+            WSTAMP(2);
+        }
+        const int n = m_idx > 0 ? m_idx : 0;
+        wave_fence();
+
+        // symbols out (optional)
+        if (sym_out) {
+#pragma unroll
+            for (int r = 0; r < (193 + LPC - 1) / LPC; ++r) {
+                const int q = gl + LPC * r;
+                if (q < n) __builtin_nontemporal_store(my.H[(hp + q) & RM], &sym_out[q]);
+            }
+            sym_out += n;
+        }
+        if (nsyms && gl == 0) nsyms[(size_t)chan * nblk + b] = n;
+        sym_total += n;
+
+        WSTAMP(3);
+        // ---- framer (m17_rx_frame.cpp:126-177) over ring symbols hp .. hp+n-1
+        int pos = (ext_lock >= 0) ? n : 0;
+        while (pos < n) {
+            WCNT(10);
+            if (flock) {
+                const int cnt = min(kFrameSyms - fclk, n - pos);
+                fclk += cnt; pos += cnt;
+                if (fclk == kFrameSyms) {
+                    fclk = 0;
+                    const int fs = hp + pos - kFrameSyms;               // the frame sits in the ring, in place
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = my.H[(fs + i) & RM];
+                    const SyncResult r = sync_check_wave(v);
+                    uint32_t flags = 0;
+                    bool parse = false, unlock = false;
+                    if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
+                    else if (sync_accept(r, true)) { flags |= M17_F_SYNC_OK; parse = true; ferr = 0; }
+                    else {
+                        ferr++;
+                        if (ferr > 5) { flags |= M17_F_LOST; unlock = true; }
+                        else parse = true;
+                    }
+                    if (parse && mode == 1) flags |= M17_F_PARSED;
+                    const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
+                    emit_record_grp(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
+                    if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
+                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kSlotFloats;
+                        store_frame_slot<LPC>(fd, r.type, gl, rg, [&](int q) { return my.H[(fs + q) & RM]; });
+                    }
+                    nrec++;
+                    if (unlock) {
+                        flock = 0;
+                        // reset_sync(): the next hunt windows must see zeros behind them
+                        wave_fence();
+                        if (gl < 8) my.H[(hp + pos - 8 + gl) & RM] = 0.0f;
+                        wave_fence();
+                    }
+                }
+            } else {
+                // hunt: candidate symbol j = pos+gl, window = ring [hp+j-7, hp+j]
+                const int jc = pos + gl;
+                const bool cand = jc < n;
+                const int jj = cand ? jc : pos;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = my.H[(hp + jj - 7 + i) & RM];
+                SyncResult r; r.type = 0; r.votes = 8; r.variance = 1.0f;
+                if (cand && hunt_compatible(v)) r = sync_check(v);           // most windows are rejected by sign
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(cand && sync_accept(r, false));
+                if (hm) {
+                    const int l = (int)__builtin_ctzll(hm);
+                    const int js = pos + l;
+                    // copy_sync(); m_fclk = 8; lock; m17_aos(): the window already is the head of the frame
+                    fclk = 8; ferr = 0; flock = 1;
+                    const int ty = __builtin_amdgcn_readlane(r.type, l), vo = __builtin_amdgcn_readlane(r.votes, l);
+                    const float va = readlane_f(r.variance, l);
+                    emit_record_grp(crecs, rec_cap, nrec, gl, (uint32_t)ty | ((uint32_t)vo << 8), M17_F_AOS, va,
+                                    block_count, (uint32_t)js);
+                    nrec++;
+                    pos = js + 1;
+                } else {
+                    pos = min(n, pos + LPC);
+                }
+            }
+        }
+        hp = (hp + n) & RM;
+        if (ext_lock < 0) block_count++;
+        WSTAMP(4);
+
+        // delay line: last 30 inputs; then the prefetched block moves in
+        {
+            const float keep_x = (gl < kTaps - 1) ? my.x[kDiscOut + gl] : 0.0f;
+            wave_fence();
+            if (gl < kTaps - 1) my.x[gl] = keep_x;
+            if (b + 1 < bend) {
+#pragma unroll
+                for (int r = 0; r < PF; ++r)
+                    my.x[kTaps - 1 + gl + LPC * r] = osrc ? (pf[r] - noff) : pf[r];     // out[i] - offset
+            }
+        }
+        wave_fence();
+    }
+
+#ifdef M17_STAMPS
+    WSTAMP(5);
+    if (chan < 4096 && gl < 8) g_chan_stamps[chan][gl] = wstamps[wave][gl < 6 ? gl : gl + 2];
+#endif
+    // ---- store state in the reference's layout
+    if (gl == 0) {
+        cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum; cs.dif = dif; cs.buff[0] = 0.0f;
+        if (ext_lock < 0) {
+            cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count; cs.sym_total = sym_total;
+            if (counts) counts[chan] = nrec;
+        }
+    }
+    if (gl < kTaps - 1) cs.buff[gl + 1] = my.x[gl];
+    if (ext_lock < 0) {
+        if (flock) { for (int q = gl; q < kFrameSyms; q += LPC) cs.fsym[q] = my.H[(hp - fclk + q) & RM]; }
+        else if (gl < 8) cs.sync[gl] = my.H[(hp - 8 + gl) & RM];
+    }
+}
+
+} // namespace m17dev

@@ -5,6 +5,7 @@
 #include "m17_sync_common.hip"
 #include "m17_sync_grp.hip"
 #include "m17_sync_duo.hip"
+#include "m17_sync_wave.hip"
 #include "m17_decode_quad.hip"
 #include "m17_book.hip"
 #include "m17_pluto.hip"
@@ -41,6 +42,10 @@ struct m17gpu_ctx {
     int fe_impl = 0;                         // 0 = by size (four lanes per channel-block), 1 = lane per channel-block, 2 = four lanes
     int sync_impl = 6;                       // 6 = timing wave + framer wave per channel up to 1,024 channels, lane groups beyond (default);
                                              // 4 = lane group per channel at every size
+    int overlap_chunks = 0;                  // > 1: channel chunks, front end of chunk k+1 beside the timing stage of chunk k (two internal streams)
+    hipStream_t aux[2] = {nullptr, nullptr}; // internal streams of the chunked mode, created on first use
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ev_chunk;        // front end of chunk k done
     std::vector<hipEvent_t> ev_pool;         // 7 events per profiled call: 5 stage marks + call start / end
     std::vector<int> ev_mode;                // mode of each profiled call
 };
@@ -180,7 +185,12 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
     // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
     int lpc = ctx->lanes_per_channel;
     if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
-    if (ctx->sync_impl == 6 && ext_lock < 0 && lpc == 64 && ctx->C <= 1024) {
+    if (ctx->sync_impl == 7) {
+        // one wave per channel, scalar control, taps in SGPRs (m17_sync_wave.hip)
+        hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(cn, WV_WAVES)), dim3(64 * WV_WAVES), 0, st,
+                           disc, offs, state, cn, nblk, mode, ext_lock, recs, recs ? rec_cap : 0,
+                           counts, syms, nsyms, fsym, b0, bcount);
+    } else if (ctx->sync_impl == 6 && ext_lock < 0 && lpc == 64 && ctx->C <= 1024) {
         // timing wave + framer wave per channel (m17_sync_duo.hip): one 8-wave workgroup per CU.  Beyond 1,024
         // channels a second workgroup per CU does not fit its registers and the lane-group kernel wins (2,048 x 50:
         // 0.350 vs 0.288 ms); the lock-forced stage entry has no framer and uses the lane-group kernel too
@@ -287,6 +297,10 @@ void m17gpu_destroy(m17gpu_ctx *ctx)
                     ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis, ctx->d_dec_hist};
     for (void *p : bufs) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (hipStream_t a : ctx->aux) if (a) (void)hipStreamDestroy(a);
     delete ctx;
 }
 
@@ -344,6 +358,37 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
                 if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
                                             d_syms, d_nsyms, st, -1, b, 1)) != M17GPU_OK) return rc;
             }
+            MARK(1);
+            MARK(2);
+        } else if (ctx->overlap_chunks > 1 && ctx->C >= 64 * ctx->overlap_chunks) {
+            // Channel chunks on two internal streams: the front end of chunk k+1 (HBM-bound) runs beside the timing
+            // stage of chunk k (issue/latency-bound).  Both streams fork from the caller's stream and join it again, so
+            // the call keeps stream semantics.  Stage marks 1/2 cannot be told apart here: both land at the join.
+            if (!ctx->aux[0]) {
+                for (hipStream_t &a : ctx->aux) HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            }
+            const int nch = ctx->overlap_chunks;
+            while ((int)ctx->ev_chunk.size() < nch) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ctx->ev_chunk.push_back(e);
+            }
+            HIPCHK(hipEventRecord(ctx->ev_fork, st));
+            HIPCHK(hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
+            HIPCHK(hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
+            const int per = ((ctx->C + nch - 1) / nch + 63) / 64 * 64;
+            for (int k = 0, c0 = 0; c0 < ctx->C; ++k, c0 += per) {
+                const int cn = std::min(per, ctx->C - c0);
+                if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, ctx->aux[0], c0, cn)) != M17GPU_OK) return rc;
+                HIPCHK(hipEventRecord(ctx->ev_chunk[k], ctx->aux[0]));
+                HIPCHK(hipStreamWaitEvent(ctx->aux[1], ctx->ev_chunk[k], 0));
+                if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
+                                            d_syms, d_nsyms, ctx->aux[1], -1, 0, -1, c0, cn)) != M17GPU_OK) return rc;
+            }
+            HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux[1]));
+            HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
             MARK(1);
             MARK(2);
         } else {
@@ -408,13 +453,14 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
     auto bad = [&]() { return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: value out of range for ") + name); };
-    if (!std::strcmp(name, "sync_impl")) { if (value != 4 && value != 6) return bad(); ctx->sync_impl = value; }
+    if (!std::strcmp(name, "sync_impl")) { if (value != 4 && value != 6 && value != 7) return bad(); ctx->sync_impl = value; }
     else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 2) return bad(); ctx->fe_impl = value; }
     else if (!std::strcmp(name, "lanes_per_channel")) {
         if (value != 0 && value != 16 && value != 32 && value != 64) return bad();
         ctx->lanes_per_channel = value;
     }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
+    else if (!std::strcmp(name, "overlap_chunks")) { if (value < 0 || value > 16) return bad(); ctx->overlap_chunks = value; }
     else return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: unknown option ") + name);
     return M17GPU_OK;
 }

@@ -1,0 +1,23 @@
+"""Phase shares of k_sync_frame_wave at the headline size (instrumented build: make -C m17_sdr_amd/csrc stamps)."""
+import sys, os, ctypes as C, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import m17_sdr_amd._lib as L
+L.LIB_PATH = L.LIB_PATH.replace("libm17gpu.so", "libm17gpu_stamps.so")
+import m17_sdr_amd as m
+Cn, nblk, T = int(sys.argv[2]) if len(sys.argv) > 2 else 16384, 12, 4
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+rx = m.Receiver(Cn, nblk)
+rx.set_option("sync_impl", 7)
+big = rx.gen_batch(nblk * T)["iq"]
+slabs = big.view(Cn, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4).contiguous()
+out = rx.alloc_outputs(nblk, want_syms=(mode == 0))
+for k in range(T): rx.rx_blocks(slabs[k], mode, out)
+torch.cuda.synchronize()
+st = np.zeros((4096, 8), np.uint64)
+m.lib().m17gpu_debug_chan_stamps(st.ctypes.data_as(C.c_void_p))
+st = st[:min(4096, Cn)].astype(np.float64)
+tot = st[:, :6].sum(1)
+names = ["round top/tick", "FIR asm", "vote+commit of round", "syms out", "framer", "block head+tail (prefetch issue, x commit)", "rounds", "tap loads"]
+print("per-wave time of the last step (ticks): min %.0f  median %.0f  p90 %.0f  max %.0f" % (tot.min(), np.median(tot), np.percentile(tot, 90), tot.max()))
+for i, n in enumerate(names):
+    print(f"  {n:45s} {st[:, i].mean() / nblk:10.1f} per block" + (f"  ({100 * st[:, i].sum() / tot.sum():.1f} %)" if i < 6 else ""))

@@ -164,7 +164,7 @@ def test_exact_arithmetic_selftest():
 @pytest.mark.parametrize("options", [
     {"sync_impl": 4, "lanes_per_channel": 64}, {"sync_impl": 4, "lanes_per_channel": 32},
     {"sync_impl": 4, "lanes_per_channel": 16}, {"sync_impl": 6}, {"sync_impl": 6, "lanes_per_channel": 32},
-    {"fe_impl": 1}, {"fe_impl": 2}])
+    {"sync_impl": 7}, {"fe_impl": 1}, {"fe_impl": 2}])
 def test_every_kernel_variant_is_bit_exact(options):
     _rx_compare(C=40, nblk=22, mode=1, ebn0=200.0, nsf=12, options=options)
     _rx_compare(C=40, nblk=9, mode=1, ebn0=9.0, nsf=5, calls=3, options=options)
@@ -499,7 +499,7 @@ def test_set_option_rejects_unknown_and_out_of_range_values():
                         ("decode_impl", 0), ("no_such_option", 1)):
         with pytest.raises(RuntimeError):
             rx.set_option(name, value)
-    for name, value in (("fe_impl", 0), ("fe_impl", 1), ("fe_impl", 2), ("sync_impl", 4), ("sync_impl", 6),
+    for name, value in (("fe_impl", 0), ("fe_impl", 1), ("fe_impl", 2), ("sync_impl", 4), ("sync_impl", 6), ("sync_impl", 7),
                         ("lanes_per_channel", 0), ("lanes_per_channel", 16)):
         rx.set_option(name, value)
     rx.close()
