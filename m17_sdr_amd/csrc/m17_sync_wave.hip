@@ -25,10 +25,12 @@ namespace m17dev {
 
 constexpr int kWvRing = 512;                   // 191 (frame in progress) + 193 (block being written) < 512
 
-struct WvChan {                                // LDS of one channel
-    float x[kTaps - 1 + kDiscOut + 2];         // delay-line history (30) + this block's 384 inputs
+struct WvChan {                                // LDS of one channel: 4 KB, the ring 2 KB-aligned (ring addresses by AND/OR)
     float H[kWvRing];                          // symbol ring
+    float x[kTaps - 1 + kDiscOut + 2];         // delay-line history (30) + this block's 384 inputs
+    float pad[1024 - kWvRing - (kTaps - 1 + kDiscOut + 2)];
 };
+static_assert(sizeof(WvChan) == 4096, "WvChan layout");
 
 // The current branch's 31 (matched, derivative) tap pairs live in s[40:101] for the whole kernel: the kernel is compiled
 // with amdgpu_num_sgpr(46), which keeps the register allocator below s40, and only the two asm blocks below touch the
@@ -80,9 +82,92 @@ __device__ __forceinline__ float readlane_f(float v, int l)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+typedef __attribute__((address_space(3))) float lds_f;
+// ring element i (any integer) of the channel whose ring starts at LDS byte address hb (2 KB-aligned)
+__device__ __forceinline__ unsigned ring_addr(int i, unsigned hb) { return (((unsigned)i << 2) & (4u * (kWvRing - 1))) | hb; }
+__device__ __forceinline__ float ring_ld(int i, unsigned hb) { return *(const lds_f *)(uintptr_t)ring_addr(i, hb); }
+__device__ __forceinline__ void ring_st(int i, unsigned hb, float v) { *(lds_f *)(uintptr_t)ring_addr(i, hb) = v; }
+
+template <int CTRL> __device__ __forceinline__ float dpp_own_f(float v)      // lanes without a source keep their value
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+// m17_sync_check (m17_rx_frame.cpp:47-81) + find_variance (:22-43) on ONE frame head held by the wave, lane l holding
+// vect[l & 7] (vs).  The six template sums run side by side in lanes 0..47: lane 8k+i starts from the exact product
+// x = vect[i] * sframe[k][i] (a sign flip, sgn = the lane's sign mask), seven row_shr:1 adds then leave the ascending
+// sum ((x0+x1)+x2)+... in lane 8k+7.  Argmax with the reference's strict '>' from (0, 0): sums clamped at 0 compare as
+// unsigned integers, so the maximum is a scalar max of six lane reads and the winner the lowest template that equals
+// it (template 0 when no sum is positive).  |vect| min / max by three DPP exchanges inside the groups of eight lanes;
+// v_max / v_min skip NaNs exactly like the reference's two compares, except a NaN in vect[0], which it keeps (-> 1.0).
+__device__ __forceinline__ SyncResult sync_check_lanes8(float vs, unsigned sgn)
+{
+    const float x = __uint_as_float(__float_as_uint(vs) ^ sgn);
+    float s = x;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) s = dpp_row_shr1(s) + x;
+    const unsigned tb = __float_as_uint(__builtin_fmaxf(s, 0.0f));
+    unsigned M = (unsigned)__builtin_amdgcn_readlane((int)tb, 7);
+#pragma unroll
+    for (int k = 1; k < 6; ++k) { const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)tb, 8 * k + 7); M = o > M ? o : M; }
+    const unsigned long long eq = __builtin_amdgcn_ballot_w64(tb == M) & 0x0000808080808080ull;
+    SyncResult r;
+    r.type = (int)__builtin_ctzll(eq) >> 3;
+    const unsigned long long neg = __builtin_amdgcn_ballot_w64(x < 0.0f);
+    r.votes = (int)__popcll((neg >> (8 * r.type)) & 0xFFull);
+    const float a = __builtin_fabsf(vs);
+    float mx = a, mn = a;
+    mx = __builtin_fmaxf(mx, dpp_own_f<0xB1>(mx)); mn = __builtin_fminf(mn, dpp_own_f<0xB1>(mn));      // lane ^ 1
+    mx = __builtin_fmaxf(mx, dpp_own_f<0x4E>(mx)); mn = __builtin_fminf(mn, dpp_own_f<0x4E>(mn));      // lane ^ 2
+    mx = __builtin_fmaxf(mx, dpp_own_f<0x141>(mx)); mn = __builtin_fminf(mn, dpp_own_f<0x141>(mn));    // row_half_mirror
+    mx = unif(mx); mn = unif(mn);
+    float var = (mx - mn) / mx;
+    if (var != var) var = 1.0f;
+    const float v0 = unif(vs);
+    if (v0 != v0) var = 1.0f;
+    r.variance = var;
+    return r;
+}
+
+// one record: five words from scalars, eleven zero words, lanes 0..15
+__device__ __forceinline__ void emit_record_wave(m17gpu_rec_dev *crecs, int rec_cap, int idx, int gl,
+                                                 uint32_t w0, uint32_t w1, float var, uint32_t block, uint32_t sympos)
+{
+    if (idx >= rec_cap) return;
+    int v = 0;
+    asm("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\t"
+        "v_writelane_b32 %0, %4, 3\n\tv_writelane_b32 %0, %5, 4"
+        : "+v"(v) : "s"(w0), "s"(w1), "s"(uni(__float_as_int(var))), "s"(block), "s"(sympos));
+    if (gl < 16) reinterpret_cast<int *>(&crecs[idx])[gl] = v;
+}
+
+// A completed frame, in place in the ring from element fs, into its slot of the decoder's workspace (layout:
+// m17_dev.h kSlotFloats; store_frame_slot, m17_sync_common.hip).  rgw = the lane's packed regroup bytes.
+__device__ __forceinline__ void store_frame_slot_wave(float *__restrict__ fd, int type, int gl, const uint32_t (&rgw)[2],
+                                                      int fs, unsigned hb)
+{
+    if (type == 2) {
+        if (gl < 8) fd[gl] = ring_ld(fs + gl, hb);
+        float4 t[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float e[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) e[c] = ring_ld(fs + 8 + (int)((rgw[r] >> (8 * c)) & 0xFFu), hb);
+            t[r] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        *reinterpret_cast<float4 *>(fd + 8 + 4 * gl) = t[0];
+        if (gl < kRegroup / 4 - 64) *reinterpret_cast<float4 *>(fd + 8 + 4 * (gl + 64)) = t[1];
+    } else if (gl < kFrameSyms / 4) {
+        const float4 t = make_float4(ring_ld(fs + 4 * gl, hb), ring_ld(fs + 4 * gl + 1, hb), ring_ld(fs + 4 * gl + 2, hb),
+                                     ring_ld(fs + 4 * gl + 3, hb));
+        *reinterpret_cast<float4 *>(fd + 4 * gl) = t;
+    }
+}
+
 constexpr int WV_WAVES = 4;                    // channels (waves) per workgroup; the waves never synchronise
 
-__global__ __launch_bounds__(64 * WV_WAVES) __attribute__((amdgpu_num_sgpr(46)))
+__global__ __launch_bounds__(64 * WV_WAVES, 6) __attribute__((amdgpu_num_sgpr(46)))
 void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                        const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
                        ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
@@ -92,12 +177,19 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
 {
     constexpr int LPC = 64;
     constexpr int RM = kWvRing - 1;
-    __shared__ __attribute__((aligned(16))) WvChan chs[WV_WAVES];
+    __shared__ __attribute__((aligned(4096))) WvChan chs[WV_WAVES];
     const int wave = uni((int)(threadIdx.x >> 6)), gl = lane_id();
     const int chan = (int)blockIdx.x * WV_WAVES + wave;
     if (chan >= C) return;
     WvChan &my = chs[wave];
+    const unsigned hb = (unsigned)uni((int)(unsigned)(uintptr_t)(lds_cfp)my.H);       // LDS byte address of the ring
     ChanState &cs = st[chan];
+    // the lane's sign mask of the frame-sync check: lane 8k+i <-> sframe[k][i] (m17_rx_frame.cpp:5-12)
+    constexpr unsigned sneg[6] = M17_SYNC_NEG_MASKS;
+    constexpr unsigned long long sneg48 = (unsigned long long)sneg[0] | ((unsigned long long)sneg[1] << 8) |
+        ((unsigned long long)sneg[2] << 16) | ((unsigned long long)sneg[3] << 24) | ((unsigned long long)sneg[4] << 32) |
+        ((unsigned long long)sneg[5] << 40);
+    const unsigned sgn = (unsigned)((sneg48 >> gl) & 1ull) << 31;
     m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
     if (!recs) rec_cap = 0;
 
@@ -212,7 +304,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                     ts_ = __builtin_amdgcn_readlane(tk, kl);
                 }
             }
-            if (gl < naccept && (m_idx + gl) >= 0) my.H[(hp + m_idx + gl) & RM] = s;
+            if (gl < naccept && (m_idx + gl) >= 0) ring_st(hp + m_idx + gl, hb, s);
             m_idx += naccept;
             sum = readlane_f(s, naccept - 1);
             dif = readlane_f(d, naccept - 1);
@@ -260,10 +352,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                 if (fclk == kFrameSyms) {
                     fclk = 0;
                     const int fs = hp + pos - kFrameSyms;               // the frame sits in the ring, in place
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = my.H[(fs + i) & RM];
-                    const SyncResult r = sync_check_wave(v);
+                    const SyncResult r = sync_check_lanes8(ring_ld(fs + (gl & 7), hb), sgn);
                     uint32_t flags = 0;
                     bool parse = false, unlock = false;
                     if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
@@ -275,10 +364,10 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                     }
                     if (parse && mode == 1) flags |= M17_F_PARSED;
                     const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
-                    emit_record_grp(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
+                    emit_record_wave(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
                     if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
                         float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kSlotFloats;
-                        store_frame_slot<LPC>(fd, r.type, gl, rg, [&](int q) { return my.H[(fs + q) & RM]; });
+                        store_frame_slot_wave(fd, r.type, gl, rg.w, fs, hb);
                     }
                     nrec++;
                     if (unlock) {
@@ -307,8 +396,8 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                     fclk = 8; ferr = 0; flock = 1;
                     const int ty = __builtin_amdgcn_readlane(r.type, l), vo = __builtin_amdgcn_readlane(r.votes, l);
                     const float va = readlane_f(r.variance, l);
-                    emit_record_grp(crecs, rec_cap, nrec, gl, (uint32_t)ty | ((uint32_t)vo << 8), M17_F_AOS, va,
-                                    block_count, (uint32_t)js);
+                    emit_record_wave(crecs, rec_cap, nrec, gl, (uint32_t)ty | ((uint32_t)vo << 8), M17_F_AOS, va,
+                                     block_count, (uint32_t)js);
                     nrec++;
                     pos = js + 1;
                 } else {
