@@ -141,12 +141,17 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
 /* Kernel-variant selectors (A/B measurement, and so the parity tests cover every variant).
  * Every accepted value selects a kernel held to bit-exact parity; anything else returns
  * M17GPU_ERR_ARG:
- *   "sync_impl"          6 = timing wave + framer wave per channel, decoupled by one block, up to
- *                            1,024 channels and lane groups beyond (default); 4 = lane group per
- *                            channel at every size
+ *   "sync_impl"          0 = by size (default): timing wave + framer wave per channel, decoupled by one
+ *                            block, up to 1,024 channels; one wave per channel with scalar control and
+ *                            the filter taps in SGPRs beyond; 7 = that kernel at every size; 6 = the
+ *                            two-wave kernel up to 1,024 channels and lane groups beyond; 4 = lane group
+ *                            per channel at every size
  *   "lanes_per_channel"  0 = by channel count (default) | 16 | 32 | 64 (lane-group kernel)
  *   "fe_impl"            0 = by size (default), 1 = lane per channel-block, 2 = four lanes per
  *                            channel-block
+ *   "overlap_chunks"     0 (default) | 2..16: channel chunks on two internal streams, the front end of
+ *                            chunk k+1 beside the timing stage of chunk k (measured: no gain)
+ *   "fe_waves_per_cu"    0 (default) | 1..32: cap of resident front-end waves per CU (overlap experiment)
  * and one functional switch:
  *   "afc"                0 (default, as the reference ships: radio.cpp:8) | 1 = radio_set_afc_on(): the
  *                            NCO mixer of m17_dsp.cpp:390-408,468 with the loop of radio.cpp:196-208 per channel.

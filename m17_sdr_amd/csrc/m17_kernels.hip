@@ -363,8 +363,17 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
     // cooperative tile load: instruction j covers rows 4j..4j+3, 16 lanes x 16 B = 256 B per row
     // (named scalars, not arrays: the chunk body is a lambda and captured arrays end up in scratch)
     const int lr = lane >> 4, c16 = lane & 15;
+#ifdef M17_STAMPS
+    // instrumented build only (scripts/exp_fe_bound.py): bit 1 = read a 31 MB cache-resident window of the input instead of
+    // the whole stream, bit 2 = do not store the discriminator stream -- what the stage costs without its HBM traffic
+    const int dbg = update_state >> 1;
+    update_state &= 1;
+#endif
     auto row_ptr = [&](int j) {
         int row = cb0 + j * 4 + lr; row = row < total ? row : total - 1;
+#ifdef M17_STAMPS
+        if (dbg & 1) row &= 4095;
+#endif
         return iq + (size_t)row * (kBlockSamples / 4) + c16;
     };
     const uint4 *g0 = row_ptr(0), *g1 = row_ptr(1), *g2 = row_ptr(2), *g3 = row_ptr(3);
@@ -444,6 +453,9 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 v = *reinterpret_cast<const float4 *>(&myo[cbl * FQ_STRIDE + q * 16 + sub * 4]);
+#ifdef M17_STAMPS
+            if (dbg & 2) { if (v.x == 123.456f) *reinterpret_cast<float4 *>(dst) = v; continue; }
+#endif
             if (valid) *reinterpret_cast<float4 *>(dst + it * 64 + q * 16 + sub * 4) = v;
         }
         wave_lds_sync();

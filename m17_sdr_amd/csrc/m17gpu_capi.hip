@@ -40,8 +40,11 @@ struct m17gpu_ctx {
     int lanes_per_channel = 0;               // lane-group timing kernel: 0 = by channel count, else 16 | 32 | 64
     bool profiling = false;
     int fe_impl = 0;                         // 0 = by size (four lanes per channel-block), 1 = lane per channel-block, 2 = four lanes
-    int sync_impl = 6;                       // 6 = timing wave + framer wave per channel up to 1,024 channels, lane groups beyond (default);
+    int sync_impl = 0;                       // 0 = by size (default): timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond;
+                                             // 6 = two-wave kernel up to 1,024 channels, lane groups beyond; 7 = wave per channel at every size;
                                              // 4 = lane group per channel at every size
+    int fe_waves_per_cu = 0;                 // experiment: cap of front-end waves per CU (0 = none)
+    int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
     int overlap_chunks = 0;                  // > 1: channel chunks, front end of chunk k+1 beside the timing stage of chunk k (two internal streams)
     hipStream_t aux[2] = {nullptr, nullptr}; // internal streams of the chunked mode, created on first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -158,9 +161,12 @@ int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc,
     // measured on MI355X (scripts/exp_scale.py): the 4-lane kernel wins at 51,200 .. 196,608 channel-blocks,
     // so it is the default at every size; fe_impl 1 keeps the one-lane kernel selectable
     const bool quad = ctx->fe_impl != 1;
+    // fe_waves_per_cu (experiment): unused dynamic LDS caps the front end's waves per CU so that a timing-stage launch on
+    // another stream finds register room beside it
+    const unsigned pad = ctx->fe_waves_per_cu > 0 ? (unsigned)std::max(0, 160 * 1024 / ctx->fe_waves_per_cu - 8704 - 64) : 0u;
     if (quad)
-        hipLaunchKernelGGL(k_frontend_q, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st,
-                           reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state);
+        hipLaunchKernelGGL(k_frontend_q, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), pad, st,
+                           reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state | (ctx->fe_debug << 1));
     else
         hipLaunchKernelGGL(k_frontend, dim3(cdiv(total, 64 * FE_WAVES)), dim3(64 * FE_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state);
@@ -185,12 +191,13 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
     // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
     int lpc = ctx->lanes_per_channel;
     if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
-    if (ctx->sync_impl == 7) {
+    const int impl = ctx->sync_impl ? ctx->sync_impl : (ctx->C <= 1024 && ext_lock < 0 ? 6 : 7);
+    if (impl == 7) {
         // one wave per channel, scalar control, taps in SGPRs (m17_sync_wave.hip)
         hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(cn, WV_WAVES)), dim3(64 * WV_WAVES), 0, st,
                            disc, offs, state, cn, nblk, mode, ext_lock, recs, recs ? rec_cap : 0,
                            counts, syms, nsyms, fsym, b0, bcount);
-    } else if (ctx->sync_impl == 6 && ext_lock < 0 && lpc == 64 && ctx->C <= 1024) {
+    } else if (impl == 6 && ext_lock < 0 && lpc == 64 && ctx->C <= 1024) {
         // timing wave + framer wave per channel (m17_sync_duo.hip): one 8-wave workgroup per CU.  Beyond 1,024
         // channels a second workgroup per CU does not fit its registers and the lane-group kernel wins (2,048 x 50:
         // 0.350 vs 0.288 ms); the lock-forced stage entry has no framer and uses the lane-group kernel too
@@ -453,13 +460,17 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
     auto bad = [&]() { return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: value out of range for ") + name); };
-    if (!std::strcmp(name, "sync_impl")) { if (value != 4 && value != 6 && value != 7) return bad(); ctx->sync_impl = value; }
+    if (!std::strcmp(name, "sync_impl")) { if (value != 0 && value != 4 && value != 6 && value != 7) return bad(); ctx->sync_impl = value; }
     else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 2) return bad(); ctx->fe_impl = value; }
     else if (!std::strcmp(name, "lanes_per_channel")) {
         if (value != 0 && value != 16 && value != 32 && value != 64) return bad();
         ctx->lanes_per_channel = value;
     }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
+#ifdef M17_STAMPS
+    else if (!std::strcmp(name, "fe_debug")) { ctx->fe_debug = value; }      // instrumented build only: WRONG results
+#endif
+    else if (!std::strcmp(name, "fe_waves_per_cu")) { if (value < 0 || value > 32) return bad(); ctx->fe_waves_per_cu = value; }
     else if (!std::strcmp(name, "overlap_chunks")) { if (value < 0 || value > 16) return bad(); ctx->overlap_chunks = value; }
     else return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: unknown option ") + name);
     return M17GPU_OK;
