@@ -70,25 +70,47 @@ def parse_args(argv=None):
 # ------------------------------------------------------------------------------------------------
 # parent: start one process per GPU (never touches HIP itself)
 # ------------------------------------------------------------------------------------------------
-def launch_ranks(args):
+def launch_ranks(args, timeout_s=1500.0):
+    """Start one fresh child per rank (never a re-exec: this process has not touched the GPU and never does), poll
+    them all, and on the first non-zero exit -- or after timeout_s -- terminate the others instead of leaving them in
+    a rendezvous or a barrier until the process-group timeout."""
     n = args.gpus
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
+        port = s.getsockname()[1]            # released here: a rank that finds it taken fails fast and all are stopped
+    import tempfile
+    procs, out0 = [], tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
                     "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if any(rcs):
-        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
-        sys.stdout.write(out0 or "")
-        return next(rc for rc in rcs if rc) or 1
-    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    t_end = time.monotonic() + timeout_s
+    bad = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = next(((r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)), None)
+        if bad or all(rc is not None for rc in rcs) or time.monotonic() > t_end:
+            break
+        time.sleep(0.2)
+    if bad or any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write(f"bench.py: rank {bad[0]} exited with {bad[1]}; the other ranks were stopped\n" if bad
+                         else f"bench.py: ranks still running after {timeout_s:.0f} s were stopped\n")
+    out0.seek(0)
+    text = out0.read()
+    if bad or any(p.returncode for p in procs):
+        sys.stdout.write(text)
+        return (bad[1] if bad else 1) or 1
+    line = [ln for ln in text.splitlines() if ln.startswith("{")]
     if not line:
         sys.stderr.write("bench.py: rank 0 printed no result line\n")
         return 1
@@ -240,17 +262,48 @@ def fanout_legs(args, torch, dist, rx, out, iq_step, world, rank, backend, C, nb
     dev = torch.device("cuda", rx.device)
     total = world * C
     full = None
-    if rank == 0:
-        full = iq_step.repeat(world, 1, 1, 1) if world > 1 else iq_step         # content is irrelevant to the transfer
     reps = 5
     t_sc, t_cp, t_ga = [], [], []
+    flag_dev = dev if backend == "nccl" else "cpu"
+
+    def all_ok(err):
+        """A leg that failed on ANY rank ends the legs on EVERY rank: one rank leaving alone would strand its peers
+        in a recv or a barrier until the process-group timeout."""
+        f = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=flag_dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        return int(f.item()) == 0
+
+    # what can fail on ONE rank alone (building the staging tensor, a bad argument) is agreed on before any rank enters
+    # the transfer: a peer already blocked in a matching send / recv could not be told afterwards
+    err = None
+    try:
+        if os.environ.get("M17_BENCH_INJECT_FANOUT_FAILURE") == str(rank):           # test hook (tests/test_a_bench_ranks.py)
+            raise RuntimeError("injected fan-out failure")
+        if rank == 0:
+            full = iq_step.repeat(world, 1, 1, 1) if world > 1 else iq_step         # content is irrelevant to the transfer
+    except Exception as e:                                       # noqa: BLE001 -- reported in the line
+        err = f"fan-out set-up on rank {rank}: {type(e).__name__}: {e}"[:300]
+    if not all_ok(err):
+        return {"fanout_error": err or "fan-out set-up failed on another rank"}
+
     for _ in range(reps + 1):
         torch.cuda.synchronize(dev); dist.barrier(); t0 = time.perf_counter()
-        mine = shard.scatter_iq(full, total, nblk, src=0, device=dev)
+        err, mine = None, None
+        try:
+            mine = shard.scatter_iq(full, total, nblk, src=0, device=dev)
+        except Exception as e:                                   # noqa: BLE001 -- reported in the line
+            err = f"scatter_iq: {type(e).__name__}: {e}"[:300]
+        if not all_ok(err):
+            return {"fanout_error": err or "scatter_iq failed on another rank"}
         torch.cuda.synchronize(dev); dist.barrier(); t1 = time.perf_counter()
         rx.rx_blocks(mine, mode, out)
         torch.cuda.synchronize(dev); dist.barrier(); t2 = time.perf_counter()
-        shard.gather_records(out["recs"], out["counts"], dst=0)
+        try:
+            shard.gather_records(out["recs"], out["counts"], dst=0)
+        except Exception as e:                                   # noqa: BLE001
+            err = f"gather_records: {type(e).__name__}: {e}"[:300]
+        if not all_ok(err):
+            return {"fanout_error": err or "gather_records failed on another rank"}
         torch.cuda.synchronize(dev); dist.barrier(); t3 = time.perf_counter()
         t_sc.append(t1 - t0); t_cp.append(t2 - t1); t_ga.append(t3 - t2)
     vals = torch.tensor([sum(t_sc[1:]) / reps, sum(t_cp[1:]) / reps, sum(t_ga[1:]) / reps], dtype=torch.float64,
@@ -322,10 +375,7 @@ def run_rank(args):
     fan = None
     if world > 1 and not args.no_fanout:
         # after the timed region and outside `value`: a failure of the transfer legs must not cost the measurement
-        try:
-            fan = fanout_legs(args, torch, dist, rx, out, iq[args.warmup % len(iq)], world, rank, backend, C, nblk, mode)
-        except Exception as e:                                   # noqa: BLE001 -- reported in the line
-            fan = {"fanout_error": f"{type(e).__name__}: {e}"[:300]}
+        fan = fanout_legs(args, torch, dist, rx, out, iq[args.warmup % len(iq)], world, rank, backend, C, nblk, mode)
 
     syms = world * C * nblk * 192 * args.steps
     msym = syms / dt / 1e6
@@ -353,6 +403,7 @@ def run_rank(args):
         line["config"]["options"] = list(args.option)
     if fan is not None:
         line["fanout"] = fan
+    if fan is not None and "fanout_ms" in fan:
         wf = ms_step + fan["fanout_ms"] + fan["gather_ms"]
         line["with_fanout"] = {"ms_per_step": round(wf, 4), "value": round(world * C * nblk * 192 / (wf * 1e-3) / 1e6, 3),
                                "unit": "Msym/s", "note": "compute step + RCCL scatter of the IQ from rank 0 + gather of the records, not overlapped"}

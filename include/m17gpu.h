@@ -141,12 +141,9 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
 /* Kernel-variant selectors (A/B measurement, and so the parity tests cover every variant).
  * Every accepted value selects a kernel held to bit-exact parity; anything else returns
  * M17GPU_ERR_ARG:
- *   "sync_impl"          0 = by size (default): timing wave + framer wave per channel, decoupled by one
+ *   "sync_impl"          0 | 6 = by size (default): timing wave + framer wave per channel, decoupled by one
  *                            block, up to 1,024 channels; one wave per channel with scalar control and
- *                            the filter taps in SGPRs beyond; 7 = that kernel at every size; 6 = the
- *                            two-wave kernel up to 1,024 channels and lane groups beyond; 4 = lane group
- *                            per channel at every size
- *   "lanes_per_channel"  0 = by channel count (default) | 16 | 32 | 64 (lane-group kernel)
+ *                            the filter taps in SGPRs beyond; 7 = that kernel at every size
  *   "fe_impl"            0 = by size (default), 1 = lane per channel-block, 2 = four lanes per
  *                            channel-block
  *   "overlap_chunks"     0 (default) | 2..16: channel chunks on two internal streams, the front end of

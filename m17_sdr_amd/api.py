@@ -50,11 +50,13 @@ class Receiver:
         import torch
         if t is None:
             return
-        assert isinstance(t, torch.Tensor) and t.is_cuda and t.device.index == self.device, \
-            f"{name} must live on cuda:{self.device}"
-        assert t.dtype == dtype and t.is_contiguous(), f"{name} must be contiguous {dtype}"
-        if shape is not None:
-            assert tuple(t.shape) == tuple(shape), f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}"
+        # exceptions, not asserts: `python -O` must not strip the only guard in front of the device pointers
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device.index == self.device):
+            raise TypeError(f"{name} must be a tensor on cuda:{self.device}")
+        if t.dtype != dtype or not t.is_contiguous():
+            raise TypeError(f"{name} must be contiguous {dtype}")
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
@@ -88,7 +90,8 @@ class Receiver:
     def rx_blocks(self, iq, mode, out):
         """iq: int16 cuda tensor [C, nblk, 1920, 2]; out: dict from alloc_outputs."""
         import torch
-        assert iq.dim() == 4, iq.shape
+        if not isinstance(iq, torch.Tensor) or iq.dim() != 4:
+            raise ValueError("iq must be a [C, nblk, 1920, 2] int16 tensor")
         nblk = int(iq.shape[1])
         self._chk(iq, torch.int16, (self.C, nblk, 1920, 2), "iq")
         self._chk_out(out, nblk)
@@ -101,8 +104,9 @@ class Receiver:
         """Outputs must have been allocated for this receiver and this block count: the symbol rows
         are nblk*193+8 floats apart and nsyms is [C, nblk]."""
         import torch
-        assert out.get("C") == self.C and out.get("nblk") == nblk, \
-            f"outputs were allocated for C={out.get('C')}, nblk={out.get('nblk')}; this call has C={self.C}, nblk={nblk}"
+        if out.get("C") != self.C or out.get("nblk") != nblk:
+            raise ValueError(f"outputs were allocated for C={out.get('C')}, nblk={out.get('nblk')}; "
+                             f"this call has C={self.C}, nblk={nblk}")
         cap = int(out["rec_cap"])
         self._chk(out["recs"], torch.uint8, (self.C, cap, 64), "out['recs']")
         self._chk(out["counts"], torch.int32, (self.C,), "out['counts']")

@@ -358,7 +358,7 @@ __device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES> &sh, int 
                    const uint8_t *__restrict__ types, int n_plain,
                    m17gpu_rec_dev *__restrict__ recs,
                    const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr, int skip_stream,
-                   int slot_floats)
+                   int slot_floats, bool spectator = false)
 {
     using Frame = QuadFrameT<(ONLY == 2) ? DQ_DECW_STREAM : DQ_DECW>;
     const int lane = lane_id(), q = lane >> 2, j = lane & 3, wave = (int)(threadIdx.x >> 6);
@@ -386,8 +386,12 @@ __device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES> &sh, int 
         const int tasks = ONLY ? (m2 + DQ_FRAMES - 1) / DQ_FRAMES
                                : (work ? (m1 + DQ_FRAMES - 1) / DQ_FRAMES + (m2 + DQ_FRAMES - 1) / DQ_FRAMES + (m3 + DQ_FRAMES - 1) / DQ_FRAMES
                                        : (n_plain + DQ_FRAMES - 1) / DQ_FRAMES);
-        if (wg * WAVES >= tasks) return;
+        if (wg * WAVES >= tasks) return;                                    // the whole workgroup leaves together
     }
+    // waves of the workgroup beyond this role's WAVES (k_decode_lists' any-type role uses two of four): they take
+    // part in the workgroup's one barrier and leave behind it -- a barrier that part of a workgroup never reaches is
+    // undefined in the HIP model, whatever the hardware does with ended waves
+    if (spectator) { __syncthreads(); return; }
     for (int i = (int)threadIdx.x; i < 96; i += 64 * WAVES) lich_row[i] = c_tab.lich_q[i];
     int row_type = 0;
     if (ONLY) {
@@ -492,8 +496,8 @@ void k_decode_lists(const float *__restrict__ fsym, const int32_t *__restrict__ 
     __shared__ union U { DqShared<2, 4> s; DqShared<0, 2> o; __device__ U() {} } sh;
     static_assert(sizeof(DqShared<0, 2>) <= sizeof(DqShared<2, 4>), "the any-type role must fit the stream role's LDS");
     if ((int)blockIdx.x < n_other) {
-        if (threadIdx.x >= 128) return;
-        decode_quad_body<0, 2>(sh.o, (int)blockIdx.x, n_other, fsym, work, nwork, cap, nullptr, 0, recs, genc, gerr, 1, slot_floats);
+        decode_quad_body<0, 2>(sh.o, (int)blockIdx.x, n_other, fsym, work, nwork, cap, nullptr, 0, recs, genc, gerr, 1, slot_floats,
+                               threadIdx.x >= 128);
     } else {
         decode_quad_body<2, 4>(sh.s, (int)blockIdx.x - n_other, (int)gridDim.x - n_other, fsym, work, nwork, cap, nullptr, 0,
                                recs, genc, gerr, 0, slot_floats);

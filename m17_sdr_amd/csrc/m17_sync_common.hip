@@ -1,8 +1,15 @@
 // m17_sync_common.hip -- helpers shared by the timing/framer kernels (included by m17gpu_capi.hip
 // after m17_kernels.hip; same namespace): LDS-only barrier and wave fence, s_memtime phase stamps
-// of the instrumented build, wave-parallel sync correlator, hunt pre-filter, packed (matched,
-// derivative) FIR.
+// of the instrumented build, frame-slot store, hunt pre-filter, the packed (matched, derivative) FIR with
+// the taps in VGPRs (two-wave kernel), the frame-sync check on lane groups of eight and the record writer.
 #pragma clang fp contract(off)
+
+// The hand-scheduled packed-FIR sequences here and in m17_fir_sgpr.inc place every v_pk_mul_f32 (op_sel) product two
+// instructions ahead of the add that reads it: one wait state is what gfx950 needs for that forwarding, and the
+// assembler does not check it.  Another target may need more, silently: refuse to build for it.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "m17_sdr_amd kernels are written and hazard-checked for gfx950 (MI355X) only"
+#endif
 
 namespace m17dev {
 
@@ -103,105 +110,127 @@ __device__ unsigned long long g_chan_stamps[4096][8];      // per channel: the p
 #define DBGCNT(i) do {} while (0)
 #endif
 
-// The control state of a channel is wave-uniform by construction; telling the
-// compiler (readfirstlane) keeps it in SGPRs and the branches on the scalar unit
-// instead of EXEC-mask control flow.
-__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
+// rx_sync_filter (m17_rx_sync.cpp:25-31): matched and derivative filter as one packed (s, d)
+// chain, ascending order, bare first product.  xs = delay line at this instant, tp = 32 tap pairs.
+//
+// The 31 packed multiplies and 30 packed adds are written out with every product formed two instructions before
+// the add that consumes it.  Left to the compiler, half of the products were consumed by the very next instruction:
+// a packed multiply with op_sel needs a wait state before a dependent read on gfx950, so the schedule carried 20
+// s_nop and 16 separate LDS waits per round of 142 issue slots.  Same instructions, same order of the adds.
+//   P, Q alternate as the product in flight; X = (x[2q], x[2q+1]); T = (matched tap, derivative tap) of one sample.
+#define M17_FIR4(A, P, Q, X0, X1, T0, T1, T2, T3)                                             \
+    asm volatile("v_pk_mul_f32 %1, %3, %5 op_sel_hi:[0,1]\n\t"                                 \
+                 "v_pk_add_f32 %0, %0, %2\n\t"                                                 \
+                 "v_pk_mul_f32 %2, %3, %6 op_sel:[1,0]\n\t"                                    \
+                 "v_pk_add_f32 %0, %0, %1\n\t"                                                 \
+                 "v_pk_mul_f32 %1, %4, %7 op_sel_hi:[0,1]\n\t"                                 \
+                 "v_pk_add_f32 %0, %0, %2\n\t"                                                 \
+                 "v_pk_mul_f32 %2, %4, %8 op_sel:[1,0]\n\t"                                    \
+                 "v_pk_add_f32 %0, %0, %1"                                                      \
+                 : "+v"(A), "=&v"(P), "+v"(Q) : "v"(X0), "v"(X1), "v"(T0), "v"(T1), "v"(T2), "v"(T3))
+__device__ __forceinline__ v2f fir_pair(const float *xs, const float4 (&tp)[16])
 {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
+    // (the offset may be odd: plain float reads, the compiler pairs them into ds_read2_b32)
+    v2f xv[16];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) xv[q] = (v2f){xs[2 * q], xs[2 * q + 1]};
+    xv[15] = (v2f){xs[30], 0.0f};
+#define M17_TLO(q) ((v2f){tp[q].x, tp[q].y})
+#define M17_THI(q) ((v2f){tp[q].z, tp[q].w})
+    v2f acc, P, Q;
+    // samples 0..3: acc = p0 (bare), then + p1, + p2; p3 stays in flight
+    asm volatile("v_pk_mul_f32 %0, %3, %5 op_sel_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 %2, %3, %6 op_sel:[1,0]\n\t"
+                 "v_pk_mul_f32 %1, %4, %7 op_sel_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %0, %0, %2\n\t"
+                 "v_pk_mul_f32 %2, %4, %8 op_sel:[1,0]\n\t"
+                 "v_pk_add_f32 %0, %0, %1"
+                 : "=&v"(acc), "=&v"(P), "=&v"(Q)
+                 : "v"(xv[0]), "v"(xv[1]), "v"(M17_TLO(0)), "v"(M17_THI(0)), "v"(M17_TLO(1)), "v"(M17_THI(1)));
+    M17_FIR4(acc, P, Q, xv[2], xv[3], M17_TLO(2), M17_THI(2), M17_TLO(3), M17_THI(3));
+    M17_FIR4(acc, P, Q, xv[4], xv[5], M17_TLO(4), M17_THI(4), M17_TLO(5), M17_THI(5));
+    M17_FIR4(acc, P, Q, xv[6], xv[7], M17_TLO(6), M17_THI(6), M17_TLO(7), M17_THI(7));
+    M17_FIR4(acc, P, Q, xv[8], xv[9], M17_TLO(8), M17_THI(8), M17_TLO(9), M17_THI(9));
+    M17_FIR4(acc, P, Q, xv[10], xv[11], M17_TLO(10), M17_THI(10), M17_TLO(11), M17_THI(11));
+    M17_FIR4(acc, P, Q, xv[12], xv[13], M17_TLO(12), M17_THI(12), M17_TLO(13), M17_THI(13));
+    // samples 28, 29, 30 and the product still in flight
+    asm volatile("v_pk_mul_f32 %1, %3, %5 op_sel_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %0, %0, %2\n\t"
+                 "v_pk_mul_f32 %2, %3, %6 op_sel:[1,0]\n\t"
+                 "v_pk_add_f32 %0, %0, %1\n\t"
+                 "v_pk_mul_f32 %1, %4, %7 op_sel_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %0, %0, %2\n\t"
+                 "v_pk_add_f32 %0, %0, %1"
+                 : "+v"(acc), "=&v"(P), "+v"(Q)
+                 : "v"(xv[14]), "v"(xv[15]), "v"(M17_TLO(14)), "v"(M17_THI(14)), "v"(M17_TLO(15)));
+#undef M17_TLO
+#undef M17_THI
+    return acc;
 }
 
 
-// m17_sync_check (m17_rx_frame.cpp:47-81) on ONE 8-symbol vector that every lane
-// of the calling wave holds: lane k < 6 accumulates template k, the in-order
-// strict-'>' argmax walks the six lanes with readlane, the votes are a ballot.
-__device__ __forceinline__ SyncResult sync_check_wave(const float v[8])
+// the lane's sign mask of the frame-sync check below: lane 8k+i <-> sframe[k][i] (m17_rx_frame.cpp:5-12)
+__device__ __forceinline__ unsigned sync_sign_mask(int lane)
 {
-    constexpr unsigned negs[6] = M17_SYNC_NEG_MASKS;
-    const int lane = lane_id();
-    unsigned neg = negs[0];
+    constexpr unsigned sneg[6] = M17_SYNC_NEG_MASKS;
+    constexpr unsigned long long sneg48 = (unsigned long long)sneg[0] | ((unsigned long long)sneg[1] << 8) |
+        ((unsigned long long)sneg[2] << 16) | ((unsigned long long)sneg[3] << 24) | ((unsigned long long)sneg[4] << 32) |
+        ((unsigned long long)sneg[5] << 40);
+    return (unsigned)((sneg48 >> lane) & 1ull) << 31;
+}
+
+template <int CTRL> __device__ __forceinline__ float dpp_own_f(float v)      // lanes without a source keep their value
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+// m17_sync_check (m17_rx_frame.cpp:47-81) + find_variance (:22-43) on ONE frame head held by the wave, lane l holding
+// vect[l & 7] (vs).  The six template sums run side by side in lanes 0..47: lane 8k+i starts from the exact product
+// x = vect[i] * sframe[k][i] (a sign flip, sgn = the lane's sign mask), seven row_shr:1 adds then leave the ascending
+// sum ((x0+x1)+x2)+... in lane 8k+7.  Argmax with the reference's strict '>' from (0, 0): sums clamped at 0 compare as
+// unsigned integers, so the maximum is a scalar max of six lane reads and the winner the lowest template that equals
+// it (template 0 when no sum is positive).  |vect| min / max by three DPP exchanges inside the groups of eight lanes;
+// v_max / v_min skip NaNs exactly like the reference's two compares, except a NaN in vect[0], which it keeps (-> 1.0).
+__device__ __forceinline__ SyncResult sync_check_lanes8(float vs, unsigned sgn)
+{
+    const float x = __uint_as_float(__float_as_uint(vs) ^ sgn);
+    float s = x;
 #pragma unroll
-    for (int k = 1; k < 6; ++k) neg = (lane == k) ? negs[k] : neg;
-    float s = (neg & 1u) ? -v[0] : v[0];
+    for (int j = 0; j < 7; ++j) s = dpp_row_shr1(s) + x;
+    const unsigned tb = __float_as_uint(__builtin_fmaxf(s, 0.0f));
+    unsigned M = (unsigned)__builtin_amdgcn_readlane((int)tb, 7);
 #pragma unroll
-    for (int i = 1; i < 8; ++i) s = (neg >> i & 1u) ? s - v[i] : s + v[i];
-    float best = 0.0f; int nmax = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const float sk = bcast_lane(s, k);
-        if (sk > best) { best = sk; nmax = k; }
-    }
-    unsigned nm = negs[0];
-#pragma unroll
-    for (int k = 1; k < 6; ++k) nm = (nmax == k) ? negs[k] : nm;
-    float mine = v[0];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) mine = (lane == i) ? v[i] : mine;
-    const bool bad = (lane < 8) && ((nm >> lane & 1u) ? (mine > 0.0f) : (mine < 0.0f));
-    const int votes = __popcll(__ballot(bad));
-    float mmin = fabsf(v[0]), mmax = mmin;
-#pragma unroll
-    for (int i = 1; i < 8; ++i) {
-        const float a = fabsf(v[i]);
-        if (a > mmax) mmax = a;
-        else if (a < mmin) mmin = a;
-    }
-    float var = (mmax - mmin) / mmax;
+    for (int k = 1; k < 6; ++k) { const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)tb, 8 * k + 7); M = o > M ? o : M; }
+    const unsigned long long eq = __builtin_amdgcn_ballot_w64(tb == M) & 0x0000808080808080ull;
+    SyncResult r;
+    r.type = (int)__builtin_ctzll(eq) >> 3;
+    const unsigned long long neg = __builtin_amdgcn_ballot_w64(x < 0.0f);
+    r.votes = (int)__popcll((neg >> (8 * r.type)) & 0xFFull);
+    const float a = __builtin_fabsf(vs);
+    float mx = a, mn = a;
+    mx = __builtin_fmaxf(mx, dpp_own_f<0xB1>(mx)); mn = __builtin_fminf(mn, dpp_own_f<0xB1>(mn));      // lane ^ 1
+    mx = __builtin_fmaxf(mx, dpp_own_f<0x4E>(mx)); mn = __builtin_fminf(mn, dpp_own_f<0x4E>(mn));      // lane ^ 2
+    mx = __builtin_fmaxf(mx, dpp_own_f<0x141>(mx)); mn = __builtin_fminf(mn, dpp_own_f<0x141>(mn));    // row_half_mirror
+    mx = unif(mx); mn = unif(mn);
+    float var = (mx - mn) / mx;
     if (var != var) var = 1.0f;
-    SyncResult r; r.type = nmax; r.votes = votes; r.variance = var;
+    const float v0 = unif(vs);
+    if (v0 != v0) var = 1.0f;
+    r.variance = var;
     return r;
 }
 
-// wave-wide max / min of a per-lane int on DPP row operations
-template <int CTRL, int RM = 0xF> __device__ __forceinline__ int dpp_keep(int v)
+// one record: five words from scalars, eleven zero words, lanes 0..15
+__device__ __forceinline__ void emit_record_wave(m17gpu_rec_dev *crecs, int rec_cap, int idx, int gl,
+                                                 uint32_t w0, uint32_t w1, float var, uint32_t block, uint32_t sympos)
 {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xF, false);      // lanes without a source keep their own value
-}
-__device__ __forceinline__ int wave_max_i(int v)
-{
-    v = max(v, dpp_keep<0x111>(v)); v = max(v, dpp_keep<0x112>(v)); v = max(v, dpp_keep<0x114>(v)); v = max(v, dpp_keep<0x118>(v));
-    v = max(v, dpp_keep<0x142, 0xA>(v)); v = max(v, dpp_keep<0x143, 0xC>(v));
-    return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ int wave_min_i(int v)
-{
-    v = min(v, dpp_keep<0x111>(v)); v = min(v, dpp_keep<0x112>(v)); v = min(v, dpp_keep<0x114>(v)); v = min(v, dpp_keep<0x118>(v));
-    v = min(v, dpp_keep<0x142, 0xA>(v)); v = min(v, dpp_keep<0x143, 0xC>(v));
-    return __builtin_amdgcn_readlane(v, 63);
+    if (idx >= rec_cap) return;
+    int v = 0;
+    asm("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\t"
+        "v_writelane_b32 %0, %4, 3\n\tv_writelane_b32 %0, %5, 4"
+        : "+v"(v) : "s"(uni((int)w0)), "s"(uni((int)w1)), "s"(uni(__float_as_int(var))), "s"(uni((int)block)), "s"(uni((int)sympos)));
+    if (gl < 16) reinterpret_cast<int *>(&crecs[idx])[gl] = v;
 }
 
-// One symbol instant: the matched (s) and derivative (d) 31-tap dot products over the
-// delay line xs[0..30], strictly in the reference's order (rx_sync_filter,
-// m17_rx_sync.cpp:25-31: bare first product, then += in ascending tap order, separate
-// multiply and add).  31 taps in four groups of 8 (last: 7); the next group's LDS reads
-// (taps are wave-uniform broadcasts) are issued before the current group's chain.
-
-// tp4: the branch's 32 (matched, derivative) tap pairs = 16 float4 (md4 is unused: kept for call compatibility)
-__device__ __forceinline__ void fir_instant(const float *xs, const float4 *tp4, const float4 *, float &s, float &d)
-{
-    // Packed form: lane pair (s, d) = (matched, derivative) accumulators, one v_pk_mul_f32 and
-    // one v_pk_add_f32 per tap -- the two chains of the reference advance in lock step, each
-    // still in its own ascending order with separate multiply and add.  Taps sit in LDS as
-    // (mf, md) pairs so a ds_read_b128 delivers two ready register pairs.
-    const float2 *xp = reinterpret_cast<const float2 *>(xs);
-    float2 xv[15];
-    float4 tp[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) tp[q] = tp4[q];
-#pragma unroll
-    for (int q = 0; q < 15; ++q) xv[q] = xp[q];
-    const float xl = xs[30];
-    v2f acc = (v2f){xv[0].x, xv[0].x} * (v2f){tp[0].x, tp[0].y};          // bare first product
-    acc = acc + (v2f){xv[0].y, xv[0].y} * (v2f){tp[0].z, tp[0].w};
-#pragma unroll
-    for (int q = 1; q < 15; ++q) {
-        acc = acc + (v2f){xv[q].x, xv[q].x} * (v2f){tp[q].x, tp[q].y};
-        acc = acc + (v2f){xv[q].y, xv[q].y} * (v2f){tp[q].z, tp[q].w};
-    }
-    acc = acc + (v2f){xl, xl} * (v2f){tp[15].x, tp[15].y};
-    s = acc.x; d = acc.y;
-}
 
 } // namespace m17dev

@@ -243,6 +243,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
     int hp = 256;
     RegroupLane<LPC> rg;
     rg.load(gl);
+    const unsigned sgn = sync_sign_mask(gl);
     // m_f_sym[0 .. fclk) is the frame in progress: ring [hp - fclk, hp); m_sync is the last 8 symbols.
     // Only positions below hp are written here: hp upward belongs to the timing wave from the start.
     if (flock) { for (int q = gl; q < fclk; q += LPC) my.H[(hp - fclk + q) & (kDuoRing - 1)] = cs.fsym[q]; }
@@ -273,10 +274,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                 if (fclk == kFrameSyms) {
                     fclk = 0;
                     const int fs = hp + pos - kFrameSyms;               // the frame sits in the ring, in place
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = my.H[(fs + i) & (kDuoRing - 1)];
-                    const SyncResult r = sync_check_grp<LPC>(v, gl, 0, 0);
+                    const SyncResult r = sync_check_lanes8(my.H[(fs + (gl & 7)) & (kDuoRing - 1)], sgn);
                     uint32_t flags = 0;
                     bool parse = false, unlock = false;
                     if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
@@ -288,7 +286,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                     }
                     if (parse && mode == 1) flags |= M17_F_PARSED;
                     const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
-                    emit_record_grp(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
+                    emit_record_wave(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
                     if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
                         float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kSlotFloats;
                         store_frame_slot<LPC>(fd, r.type, gl, rg, [&](int q) { return my.H[(fs + q) & (kDuoRing - 1)]; });
@@ -320,7 +318,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                     fclk = 8; ferr = 0; flock = 1;
                     const int ty = __shfl(r.type, l, 64), vo = __shfl(r.votes, l, 64);
                     const float va = __shfl(r.variance, l, 64);
-                    emit_record_grp(crecs, rec_cap, nrec, gl, (uint32_t)ty | ((uint32_t)vo << 8), M17_F_AOS, va,
+                    emit_record_wave(crecs, rec_cap, nrec, gl, (uint32_t)ty | ((uint32_t)vo << 8), M17_F_AOS, va,
                                     block_count, (uint32_t)js);
                     nrec++;
                     pos = js + 1;

@@ -3,8 +3,8 @@
 //
 // Reference: m17_rx_sync_samples (m17_rx_sync.cpp:77-99), m17_rx_sym (m17_rx_frame.cpp:126-177).
 //
-// Why (round-2 measurements): the lane-group kernel (four channels per wave, 16
-// lanes each, taps in 62 VGPRs) ran at two waves per SIMD -- 241 VGPRs, 63 KB of LDS per workgroup --
+// Why (round-2 measurements): the lane-group kernel it replaces (four channels per wave,
+// 16 lanes each, taps in 62 VGPRs; retired in round 3) ran at two waves per SIMD -- 241 VGPRs, 63 KB of LDS per workgroup --
 // and at one instruction per ~9 cycles per wave: bound by latency, not by its 890 instructions per
 // channel-block.  Its control variables are equal within a lane group but differ between the groups of
 // a wave, so every branch is EXEC-mask divergence and every wave executes the union of its four
@@ -88,59 +88,6 @@ __device__ __forceinline__ unsigned ring_addr(int i, unsigned hb) { return (((un
 __device__ __forceinline__ float ring_ld(int i, unsigned hb) { return *(const lds_f *)(uintptr_t)ring_addr(i, hb); }
 __device__ __forceinline__ void ring_st(int i, unsigned hb, float v) { *(lds_f *)(uintptr_t)ring_addr(i, hb) = v; }
 
-template <int CTRL> __device__ __forceinline__ float dpp_own_f(float v)      // lanes without a source keep their value
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-
-// m17_sync_check (m17_rx_frame.cpp:47-81) + find_variance (:22-43) on ONE frame head held by the wave, lane l holding
-// vect[l & 7] (vs).  The six template sums run side by side in lanes 0..47: lane 8k+i starts from the exact product
-// x = vect[i] * sframe[k][i] (a sign flip, sgn = the lane's sign mask), seven row_shr:1 adds then leave the ascending
-// sum ((x0+x1)+x2)+... in lane 8k+7.  Argmax with the reference's strict '>' from (0, 0): sums clamped at 0 compare as
-// unsigned integers, so the maximum is a scalar max of six lane reads and the winner the lowest template that equals
-// it (template 0 when no sum is positive).  |vect| min / max by three DPP exchanges inside the groups of eight lanes;
-// v_max / v_min skip NaNs exactly like the reference's two compares, except a NaN in vect[0], which it keeps (-> 1.0).
-__device__ __forceinline__ SyncResult sync_check_lanes8(float vs, unsigned sgn)
-{
-    const float x = __uint_as_float(__float_as_uint(vs) ^ sgn);
-    float s = x;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) s = dpp_row_shr1(s) + x;
-    const unsigned tb = __float_as_uint(__builtin_fmaxf(s, 0.0f));
-    unsigned M = (unsigned)__builtin_amdgcn_readlane((int)tb, 7);
-#pragma unroll
-    for (int k = 1; k < 6; ++k) { const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)tb, 8 * k + 7); M = o > M ? o : M; }
-    const unsigned long long eq = __builtin_amdgcn_ballot_w64(tb == M) & 0x0000808080808080ull;
-    SyncResult r;
-    r.type = (int)__builtin_ctzll(eq) >> 3;
-    const unsigned long long neg = __builtin_amdgcn_ballot_w64(x < 0.0f);
-    r.votes = (int)__popcll((neg >> (8 * r.type)) & 0xFFull);
-    const float a = __builtin_fabsf(vs);
-    float mx = a, mn = a;
-    mx = __builtin_fmaxf(mx, dpp_own_f<0xB1>(mx)); mn = __builtin_fminf(mn, dpp_own_f<0xB1>(mn));      // lane ^ 1
-    mx = __builtin_fmaxf(mx, dpp_own_f<0x4E>(mx)); mn = __builtin_fminf(mn, dpp_own_f<0x4E>(mn));      // lane ^ 2
-    mx = __builtin_fmaxf(mx, dpp_own_f<0x141>(mx)); mn = __builtin_fminf(mn, dpp_own_f<0x141>(mn));    // row_half_mirror
-    mx = unif(mx); mn = unif(mn);
-    float var = (mx - mn) / mx;
-    if (var != var) var = 1.0f;
-    const float v0 = unif(vs);
-    if (v0 != v0) var = 1.0f;
-    r.variance = var;
-    return r;
-}
-
-// one record: five words from scalars, eleven zero words, lanes 0..15
-__device__ __forceinline__ void emit_record_wave(m17gpu_rec_dev *crecs, int rec_cap, int idx, int gl,
-                                                 uint32_t w0, uint32_t w1, float var, uint32_t block, uint32_t sympos)
-{
-    if (idx >= rec_cap) return;
-    int v = 0;
-    asm("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\t"
-        "v_writelane_b32 %0, %4, 3\n\tv_writelane_b32 %0, %5, 4"
-        : "+v"(v) : "s"(w0), "s"(w1), "s"(uni(__float_as_int(var))), "s"(block), "s"(sympos));
-    if (gl < 16) reinterpret_cast<int *>(&crecs[idx])[gl] = v;
-}
-
 // A completed frame, in place in the ring from element fs, into its slot of the decoder's workspace (layout:
 // m17_dev.h kSlotFloats; store_frame_slot, m17_sync_common.hip).  rgw = the lane's packed regroup bytes.
 __device__ __forceinline__ void store_frame_slot_wave(float *__restrict__ fd, int type, int gl, const uint32_t (&rgw)[2],
@@ -184,12 +131,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
     WvChan &my = chs[wave];
     const unsigned hb = (unsigned)uni((int)(unsigned)(uintptr_t)(lds_cfp)my.H);       // LDS byte address of the ring
     ChanState &cs = st[chan];
-    // the lane's sign mask of the frame-sync check: lane 8k+i <-> sframe[k][i] (m17_rx_frame.cpp:5-12)
-    constexpr unsigned sneg[6] = M17_SYNC_NEG_MASKS;
-    constexpr unsigned long long sneg48 = (unsigned long long)sneg[0] | ((unsigned long long)sneg[1] << 8) |
-        ((unsigned long long)sneg[2] << 16) | ((unsigned long long)sneg[3] << 24) | ((unsigned long long)sneg[4] << 32) |
-        ((unsigned long long)sneg[5] << 40);
-    const unsigned sgn = (unsigned)((sneg48 >> gl) & 1ull) << 31;
+    const unsigned sgn = sync_sign_mask(gl);
     m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
     if (!recs) rec_cap = 0;
 

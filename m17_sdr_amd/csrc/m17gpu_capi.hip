@@ -3,7 +3,6 @@
 #include "m17_host.h"
 #include "m17_kernels.hip"
 #include "m17_sync_common.hip"
-#include "m17_sync_grp.hip"
 #include "m17_sync_duo.hip"
 #include "m17_sync_wave.hip"
 #include "m17_decode_quad.hip"
@@ -21,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <new>
+#include <memory>
 
 using namespace m17dev;
 
@@ -37,12 +37,10 @@ struct m17gpu_ctx {
     uint16_t *d_genc = nullptr, *d_gerr = nullptr, *d_crc_basis = nullptr;
     uint32_t *d_dec_hist = nullptr;          // [C][32] history of the wide-band decimator
     int afc = 0;                             // 1 = AFC on (radio_set_afc_on): block-sequential front end
-    int lanes_per_channel = 0;               // lane-group timing kernel: 0 = by channel count, else 16 | 32 | 64
     bool profiling = false;
     int fe_impl = 0;                         // 0 = by size (four lanes per channel-block), 1 = lane per channel-block, 2 = four lanes
-    int sync_impl = 0;                       // 0 = by size (default): timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond;
-                                             // 6 = two-wave kernel up to 1,024 channels, lane groups beyond; 7 = wave per channel at every size;
-                                             // 4 = lane group per channel at every size
+    int sync_impl = 0;                       // 0 | 6 = timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond (default);
+                                             // 7 = wave per channel at every size
     int fe_waves_per_cu = 0;                 // experiment: cap of front-end waves per CU (0 = none)
     int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
     int overlap_chunks = 0;                  // > 1: channel chunks, front end of chunk k+1 beside the timing stage of chunk k (two internal streams)
@@ -86,7 +84,11 @@ struct DeviceScope {
 int upload_tables(m17gpu_ctx *ctx)
 {
     const m17::Tables &T = m17::tables();
-    static DevTables h;                      // too large for the stack of some callers
+    // per-call scratch on the heap (too large for the stack of some callers; a function-static one made two host
+    // threads creating contexts for two GPUs race)
+    std::unique_ptr<DevTables> hp(new (std::nothrow) DevTables);
+    if (!hp) return fail(M17GPU_ERR_NOMEM, "upload_tables: out of host memory");
+    DevTables &h = *hp;
     std::memset(&h, 0, sizeof h);
     for (int p = 0; p < kPhases; ++p)
         for (int j = 0; j < kTaps; ++j) {
@@ -188,29 +190,18 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
     float *syms = d_syms ? d_syms + (size_t)c0 * M17_SYM_STRIDE(nblk) : nullptr;
     int32_t *nsyms = d_nsyms ? d_nsyms + (size_t)c0 * nblk : nullptr;
     float *fsym = ctx->d_fsym + (size_t)c0 * rec_cap * kSlotFloats;
-    // lanes per channel: keep >= ~1 wave per SIMD (1,024 SIMDs) but share the control code when channels abound
-    int lpc = ctx->lanes_per_channel;
-    if (lpc != 16 && lpc != 32 && lpc != 64) lpc = ctx->C <= 2048 ? 64 : (ctx->C <= 4096 ? 32 : 16);   // <= 2 waves per SIMD (measured)
-    const int impl = ctx->sync_impl ? ctx->sync_impl : (ctx->C <= 1024 && ext_lock < 0 ? 6 : 7);
-    if (impl == 7) {
-        // one wave per channel, scalar control, taps in SGPRs (m17_sync_wave.hip)
-        hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(cn, WV_WAVES)), dim3(64 * WV_WAVES), 0, st,
-                           disc, offs, state, cn, nblk, mode, ext_lock, recs, recs ? rec_cap : 0,
-                           counts, syms, nsyms, fsym, b0, bcount);
-    } else if (impl == 6 && ext_lock < 0 && lpc == 64 && ctx->C <= 1024) {
-        // timing wave + framer wave per channel (m17_sync_duo.hip): one 8-wave workgroup per CU.  Beyond 1,024
-        // channels a second workgroup per CU does not fit its registers and the lane-group kernel wins (2,048 x 50:
-        // 0.350 vs 0.288 ms); the lock-forced stage entry has no framer and uses the lane-group kernel too
+    // two-wave kernel (timing wave + framer wave per channel, m17_sync_duo.hip: one 8-wave workgroup per CU) up to
+    // 1,024 channels -- a second workgroup per CU does not fit its registers; beyond that, and for the lock-forced
+    // stage entry, which has no framer, one wave per channel with scalar control (m17_sync_wave.hip)
+    const bool duo = (ctx->sync_impl == 0 || ctx->sync_impl == 6) && ctx->C <= 1024 && ext_lock < 0;
+    if (duo)
         hipLaunchKernelGGL(k_sync_frame_duo, dim3(cdiv(cn, 4)), dim3(512), 0, st,
                            disc, offs, state, cn, nblk, mode, recs, recs ? rec_cap : 0,
                            counts, syms, nsyms, fsym, b0, bcount);
-    } else {
-#define LAUNCH_GRP(L) hipLaunchKernelGGL(k_sync_frame_grp<L>, dim3(cdiv(cn, GrpCfg<L>::CPW)), dim3(256), 0, st, \
-                           disc, offs, state, cn, nblk, mode, ext_lock, recs, recs ? rec_cap : 0,                \
-                           counts, syms, nsyms, fsym, b0, bcount)
-        if (lpc == 64) LAUNCH_GRP(64); else if (lpc == 32) LAUNCH_GRP(32); else LAUNCH_GRP(16);
-#undef LAUNCH_GRP
-    }
+    else
+        hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(cn, WV_WAVES)), dim3(64 * WV_WAVES), 0, st,
+                           disc, offs, state, cn, nblk, mode, ext_lock, recs, recs ? rec_cap : 0,
+                           counts, syms, nsyms, fsym, b0, bcount);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -291,7 +282,13 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
 #undef ALLOC
     rc = m17gpu_reset(ctx, nullptr);
     if (rc != M17GPU_OK) { m17gpu_destroy(ctx); return rc; }
-    HIPCHK(hipDeviceSynchronize());
+    {
+        const hipError_t e_ = hipDeviceSynchronize();
+        if (e_ != hipSuccess) {
+            m17gpu_destroy(ctx);
+            return fail(M17GPU_ERR_HIP, std::string("m17gpu_create: ") + hipGetErrorString(e_));
+        }
+    }
     *out = ctx;
     return M17GPU_OK;
 }
@@ -328,14 +325,15 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
 {
     if (!ctx || !d_iq || nblk <= 0 || nblk > ctx->max_blocks || rec_cap < 0)
         return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: bad argument (nblk must be 1..max_blocks)");
+    if (mode != 0 && mode != 1) return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: mode must be 0 (front end) or 1 (full chain)");
     ON_CTX_DEVICE(ctx);
     // mode 1: every framer event must get its record -- an event without one would also lose its frame symbols,
     // and with them the LICH / counter / packet bookkeeping the reference does for that frame
-    if ((mode & 0xFF) == 1 && (!d_recs || rec_cap < 2 * nblk + 2 || rec_cap > ctx->rec_cap_max))
+    if (mode == 1 && (!d_recs || rec_cap < 2 * nblk + 2 || rec_cap > ctx->rec_cap_max))
         return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: mode 1 needs d_recs and 2*nblk+2 <= rec_cap <= 2*max_blocks+2");
     hipStream_t st = S(stream);
     int rc;
-    const bool full = (mode & 0xFF) == 1;
+    const bool full = mode == 1;
     if (full) HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t) * 4, st));
     hipEvent_t *ev = nullptr;
     if (ctx->profiling && ctx->ev_mode.size() < 512) {
@@ -345,7 +343,7 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
             HIPCHK(hipEventCreate(&e));
             ctx->ev_pool.push_back(e);
         }
-        ctx->ev_mode.push_back(mode & 0xFF);
+        ctx->ev_mode.push_back(mode);
         ev = &ctx->ev_pool[base];
     }
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
@@ -460,12 +458,8 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
     auto bad = [&]() { return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: value out of range for ") + name); };
-    if (!std::strcmp(name, "sync_impl")) { if (value != 0 && value != 4 && value != 6 && value != 7) return bad(); ctx->sync_impl = value; }
+    if (!std::strcmp(name, "sync_impl")) { if (value != 0 && value != 6 && value != 7) return bad(); ctx->sync_impl = value; }
     else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 2) return bad(); ctx->fe_impl = value; }
-    else if (!std::strcmp(name, "lanes_per_channel")) {
-        if (value != 0 && value != 16 && value != 32 && value != 64) return bad();
-        ctx->lanes_per_channel = value;
-    }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
 #ifdef M17_STAMPS
     else if (!std::strcmp(name, "fe_debug")) { ctx->fe_debug = value; }      // instrumented build only: WRONG results

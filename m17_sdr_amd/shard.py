@@ -57,17 +57,20 @@ def gather_records(recs, counts, dst=0, group=None):
 
 
 def scatter_iq(iq_full, n_channels, nblk, src=0, group=None, device=None):
-    """Fan the [C, nblk, 1920, 2] int16 IQ held by `src` out to the owning ranks: one point-to-point
-    send per peer.  Non-source ranks pass iq_full=None.  Returns this rank's shard
-    [hi-lo, nblk, 1920, 2] on `device` (default: the source tensor's device / the current device)."""
+    """Fan the [C, nblk, 1920, 2] int16 IQ held by `src` out to the owning ranks point to point, as ONE grouped
+    operation (batch_isend_irecv = ncclGroupStart / ncclSend x (world-1) / ncclGroupEnd on RCCL): the sends to
+    the seven peers are in flight together, each on its own xGMI link.  Non-source ranks pass iq_full=None.
+    Returns this rank's shard [hi-lo, nblk, 1920, 2] on `device` (default: the source tensor's device / the
+    current device)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = channel_range(rank, world, n_channels)
     direct = _moves_device_tensors(group)
+    ops, keep = [], []
     if rank == src:
-        assert iq_full is not None and tuple(iq_full.shape) == (n_channels, nblk, 1920, 2) and iq_full.dtype == torch.int16
+        if iq_full is None or tuple(iq_full.shape) != (n_channels, nblk, 1920, 2) or iq_full.dtype != torch.int16:
+            raise ValueError(f"the source rank passes the full IQ tensor [{n_channels}, {nblk}, 1920, 2] int16")
         home = device if device is not None else iq_full.device
-        reqs, keep = [], []
         for r in range(world):
             a, b = channel_range(r, world, n_channels)
             if r != src and b > a:
@@ -75,15 +78,16 @@ def scatter_iq(iq_full, n_channels, nblk, src=0, group=None, device=None):
                 if not direct and part.device.type != "cpu":
                     part = part.cpu()
                 keep.append(part)
-                reqs.append(dist.isend(part, dst=r, group=group))
+                ops.append(dist.P2POp(dist.isend, part, r, group))
         mine = iq_full[lo:hi].to(home)
-        for q in reqs:
-            q.wait()
-        return mine
-    assert iq_full is None, "only the source rank passes the full IQ tensor"
-    home = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-    wire = home if direct else torch.device("cpu")
-    mine = torch.empty((hi - lo, nblk, 1920, 2), dtype=torch.int16, device=wire)
-    if hi > lo:
-        dist.recv(mine, src=src, group=group)
+    else:
+        if iq_full is not None:
+            raise ValueError("only the source rank passes the full IQ tensor")
+        home = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        wire = home if direct else torch.device("cpu")
+        mine = torch.empty((hi - lo, nblk, 1920, 2), dtype=torch.int16, device=wire)
+        if hi > lo:
+            ops.append(dist.P2POp(dist.irecv, mine, src, group))
+    for q in (dist.batch_isend_irecv(ops) if ops else []):
+        q.wait()
     return mine.to(home)
