@@ -55,6 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--signal-gb", type=float, default=40.0, help="distinct signal kept in HBM per GPU before the stream wraps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fir-stage", action="store_true", help="skip the nested configs[1] FIR-stage measurement")
+    ap.add_argument("--no-noisy", action="store_true", help="skip the nested measurement on the AWGN workload of configs[3]")
     ap.add_argument("--no-fanout", action="store_true", help="N>1: skip the separately timed RCCL scatter/gather legs")
     ap.add_argument("--no-syms", action="store_true", help="front end: do not write the symbol stream")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
@@ -161,10 +162,7 @@ def cpu_baseline(mode, sig):
     """The CPU oracle (port of the reference path) on a bounded sample of the same workload, all host
     threads of this job's share, same run."""
     from tests import oracle
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
+    avail, phys, smt = host_cores()
     cores = max(1, min(avail, 16))          # the GPU box gives one GPU's job a share of 16 host threads
     nch = sig["iq"].shape[0]
     iq = np.ascontiguousarray(sig["iq"][:nch])
@@ -183,6 +181,8 @@ def cpu_baseline(mode, sig):
         ch1.rx_blocks(iq[:1], mode=mode, want_syms=False, nthreads=1)
     us_blk = (time.perf_counter() - t1) / (8 * iq.shape[1]) * 1e6
     return {"value": round(syms / t_used / 1e6, 3), "unit": "Msym/s", "cores": cores, "kind": "port",
+            "host": {"threads_usable_by_this_job": avail, "physical_cores": phys, "hardware_threads": smt,
+                     "note": "cores = OpenMP threads used; with SMT two of them may share a physical core"},
             "sample": f"{nch} channels x {iq.shape[1]} blocks x {reps} passes of the same synthetic IQ, "
                       f"{'full chain' if mode == 1 else 'front end'}, OpenMP over channels ({t_used:.2f} s wall); "
                       f"1 thread: {us_blk:.1f} us/block",
@@ -251,6 +251,67 @@ def fir_stage(args, torch, device):
             "frac": ro["frac"], "achieved": ro["achieved"], "traffic": ro["traffic"], "avg_ms": ro["avg_ms"],
             "kernel_sum_ms": ro["kernel_sum_ms"], "algorithmic_bytes_per_channel_block": BYTES_FRONT,
             "channel_blocks_per_launch": C * nblk, "steps": steps, "target_frac": 0.40}
+
+
+def noisy_leg(args, torch, device, C, nblk, ebn0=8.0):
+    """The same step on the workload BASELINE configs[3] names: band-limited AWGN (12.5 kHz channel noise, Eb/N0 8 dB),
+    so that the hunt path of the framer and a decoder load that depends on lock state are on record next to the
+    noiseless headline.  One continuous stream per channel, cut into steps like the headline."""
+    import m17_sdr_amd as m
+    steps, warm = 20, 3
+    rx = m.Receiver(C, nblk, device=device)
+    for kv in args.option:
+        name, value = kv.split("=")
+        rx.set_option(name, int(value))
+    T = steps + warm
+    big = rx.gen_batch(nblk * T, n_stream_frames=40, ebn0_db=ebn0, noise_cutoff_hz=6250.0)["iq"]
+    torch.cuda.synchronize(device)
+    slabs = torch.empty((T, C, nblk, 1920, 2), dtype=torch.int16, device=big.device)
+    slabs.copy_(big.view(C, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4))
+    del big
+    out = rx.alloc_outputs(nblk)
+    for k in range(warm):
+        rx.rx_blocks(slabs[k], 1, out)
+    torch.cuda.synchronize(device)
+    rx.set_profiling(True)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        rx.rx_blocks(slabs[warm + k], 1, out)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    rx.set_profiling(False)
+    kms, ncalls = rx.kernel_ms()
+    locked = int(rx.lock().sum())
+    rx.close()
+    del slabs
+    torch.cuda.empty_cache()
+    ro = roofline_obj(kms, ncalls, 1, C * nblk, f"full-noisy:{C}x{nblk}")
+    return {"workload": f"full chain, {C:,} channels x {nblk} blocks, band-limited AWGN at Eb/N0 {ebn0:g} dB (BASELINE configs[3])",
+            "ebn0_db": ebn0, "ms": round(dt / steps * 1e3, 4), "value": round(C * nblk * 192 * steps / dt / 1e6, 3),
+            "unit": "Msym/s", "frac": ro["frac"], "achieved": ro["achieved"], "avg_ms": ro["avg_ms"],
+            "kernel_sum_ms": ro["kernel_sum_ms"], "steps": steps, "channels_locked_at_end": locked}
+
+
+def host_cores():
+    """(threads this job may use, physical cores and SMT threads of the host as /proc/cpuinfo lists them)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    phys, threads = set(), 0
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("processor"):
+                threads += 1
+            elif ln.startswith("physical id"):
+                pid = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":")[1].strip()
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    return avail, (len(phys) or None), (threads or None)
 
 
 def fanout_legs(args, torch, dist, rx, out, iq_step, world, rank, backend, C, nblk, mode):
@@ -411,6 +472,8 @@ def run_rank(args):
         rx.close()
         del iq
         torch.cuda.empty_cache()
+        if world == 1 and not args.no_noisy and mode == 1 and args.ebn0 >= 100.0:
+            line["noisy"] = noisy_leg(args, torch, local, C, nblk)
         if world == 1 and not args.no_fir_stage and mode == 1:
             line["fir_stage"] = fir_stage(args, torch, local)
         if not args.no_cpu_baseline and world == 1:

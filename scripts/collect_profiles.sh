@@ -10,10 +10,10 @@ O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for wl in full frontend; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$wl -- python3 $R/bench.py --workload $wl --no-cpu-baseline --no-fir-stage > $O/bench_trace_$wl.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$wl -- python3 $R/bench.py --workload $wl --no-cpu-baseline --no-fir-stage --no-noisy > $O/bench_trace_$wl.log 2>&1
   python3 $R/scripts/prof_summary.py $O/trace_$wl > $O/kernel_stats_$wl.txt
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${c}_$wl -- python3 $R/bench.py --workload $wl --no-cpu-baseline --no-fir-stage --steps 3 --warmup 1 > $O/bench_pmc_${c}_$wl.log 2>&1
+    timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${c}_$wl -- python3 $R/bench.py --workload $wl --no-cpu-baseline --no-fir-stage --no-noisy --steps 3 --warmup 1 > $O/bench_pmc_${c}_$wl.log 2>&1
     python3 $R/scripts/pmc_summary.py $O/pmc_${c}_$wl > $O/pmc_${c}_$wl.txt
   done
   rm -rf $O/trace_$wl $O/pmc_FETCH_SIZE_$wl $O/pmc_WRITE_SIZE_$wl

@@ -22,7 +22,7 @@ def test_bench_starts_its_own_ranks_gloo_rehearsal():
     env = dict(os.environ, M17_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-                        "--channels", "96", "--blocks", "6", "--no-cpu-baseline"],
+                        "--channels", "96", "--blocks", "6", "--no-cpu-baseline", "--no-noisy"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -38,7 +38,7 @@ def test_bench_line_survives_a_failing_fanout_leg():
     env = dict(os.environ, M17_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4", M17_BENCH_INJECT_FANOUT_FAILURE="1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--channels", "64", "--blocks", "4", "--no-cpu-baseline"],
+                        "--channels", "64", "--blocks", "4", "--no-cpu-baseline", "--no-noisy"],
                        env=env, capture_output=True, text=True, timeout=150)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

