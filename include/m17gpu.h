@@ -219,6 +219,38 @@ typedef struct {
 } m17gpu_lsf_fields;
 int m17gpu_parse_lsf(const uint8_t lsf[30], m17gpu_lsf_fields *out);
 
+/* ---------------- multi-GPU fan-out for a C / C++ host (RCCL over xGMI) ----------------
+ * The path shards by channel (the reference has one channel per process, m17_tx_rx.cpp:28-40; here rank r of
+ * `world` owns the contiguous range m17gpu_shard_range gives and a context of exactly that many channels).  No
+ * collective sits on the data path; per step the ingest rank fans the IQ out and the records come back:
+ *   m17gpu_shard_scatter_iq      src_rank holds d_iq_all [n_channels_total][nblk][1920][2]; every rank receives its
+ *                                range into d_iq_mine [C][nblk][1920][2].  ONE ncclGroupStart/End: the sends to
+ *                                the world-1 peers are in flight together, one xGMI link each.
+ *   m17gpu_shard_gather_records  every rank's d_recs_mine [C][rec_cap] + d_counts_mine [C] land on dst_rank in
+ *                                d_recs_all [n_channels_total][rec_cap], d_counts_all [n_channels_total].
+ * comm is the caller's ncclComm_t (passed as void* so that this header needs no RCCL header); both calls are
+ * enqueued on `stream` and return at once.  RCCL is looked up in the process at first use (the copy already
+ * loaded, else librccl.so.1); without it these two entries return M17GPU_ERR_HIP and nothing else is affected. */
+void m17gpu_shard_range(int rank, int world, int n_channels_total, int *lo, int *hi);
+int m17gpu_shard_scatter_iq(m17gpu_ctx *ctx, void *comm, int rank, int world, int src_rank,
+                            const int16_t *d_iq_all, int n_channels_total, int nblk, int16_t *d_iq_mine, void *stream);
+int m17gpu_shard_gather_records(m17gpu_ctx *ctx, void *comm, int rank, int world, int dst_rank,
+                                const m17gpu_rec *d_recs_mine, const int32_t *d_counts_mine, int rec_cap,
+                                int n_channels_total, m17gpu_rec *d_recs_all, int32_t *d_counts_all, void *stream);
+
+/* ---------------- output wire format on the device ----------------
+ * m17gpu_set_net_output attaches the sink of decode_stream_frame (m17_rx_parse.cpp:151-154 ->
+ * m17_net_new_rx_data m17_net.cpp:53-74) to the context: while d_net != NULL every m17gpu_rx_blocks(mode 1)
+ * call writes, for each record flagged M17GPU_F_DELIVERED, the 54-byte frame of m17gpu_format_net_frame into
+ *   d_net [C][rec_cap][56]   at [channel][index of that record]   (rows of 56 bytes, the frame is the first 54)
+ * built by the bookkeeping kernel from (stream id, m_lsf[1] AS IT STOOD AT THAT FRAME, fn, payload); rec_cap is
+ * that of the m17gpu_rx_blocks call.  stream id = d_stream_ids[channel] (0 when NULL) + the channel's frame-id
+ * epoch (the event counter that stands in for the reference's rand(), m17_rx_parse.cpp:10-12), mod 2^16.
+ * dst_override as in m17gpu_format_net_frame.  Rows of other records are left untouched.  d_net = NULL detaches. */
+int m17gpu_set_net_output(m17gpu_ctx *ctx, uint8_t *d_net, const uint16_t *d_stream_ids, uint64_t dst_override);
+/* m17gpu_parse_lsf for n LSFs resident on the device: d_lsf [n][30] -> d_out [n] (64-byte structs) */
+int m17gpu_parse_lsf_batch(m17gpu_ctx *ctx, const uint8_t *d_lsf, m17gpu_lsf_fields *d_out, int n, void *stream);
+
 /* ---------------- synthetic signal source (host) ----------------
  * A restatement of the reference transmitter (framer m17_tx_routines.cpp:24-255,
  * 4-FSK modulator m17_modulate.cpp:22-86, 10 samples/symbol) used to produce

@@ -69,6 +69,11 @@ SIGNATURES = {
     "m17gpu_get_constant": (_i, [C.c_char_p, _vp, _i]),
     "m17gpu_format_net_frame": (_i, [C.c_uint16, _vp, C.c_uint16, _vp, _u64, _vp]),
     "m17gpu_parse_lsf": (_i, [_vp, _vp]),
+    "m17gpu_set_net_output": (_i, [_vp, _vp, _vp, _u64]),
+    "m17gpu_shard_range": (None, [_i, _i, _i, _vp, _vp]),
+    "m17gpu_shard_scatter_iq": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "m17gpu_shard_gather_records": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "m17gpu_parse_lsf_batch": (_i, [_vp, _vp, _vp, _i, _vp]),
     "m17gen_channel": (_i, [C.POINTER(GenParams), _i, _vp, _vp, _vp, _i]),
     "m17gen_batch": (_i, [_i, _u64, _i, _i, _i, C.c_float, C.c_float, _i, _vp, _vp, _vp, _i, _vp, _i]),
     "m17gen_stream_frame_dibits": (_i, [_vp, _i, C.c_uint16, _vp, _vp]),

@@ -206,6 +206,34 @@ class Receiver:
         _check(lib().m17gpu_golay_decode(self._ctx, _ptr(words), _ptr(out), n, self._stream()), "m17gpu_golay_decode")
         return out
 
+    # ---- output wire format on the device -----------------------
+    def set_net_output(self, rec_cap=None, stream_ids=None, dst_override=0):
+        """Attach the network sink: returns the uint8 tensor [C, rec_cap, 56] that rx_blocks(mode 1) fills with the
+        54-byte M17-over-IP frame of every DELIVERED record (m17_net.cpp:25-74).  rec_cap must be the one of the
+        outputs passed to rx_blocks.  stream_ids: optional uint16-valued int16/uint16 tensor [C]."""
+        import torch
+        rec_cap = self.rec_cap_max if rec_cap is None else int(rec_cap)
+        net = torch.zeros((self.C, rec_cap, 56), dtype=torch.uint8, device=f"cuda:{self.device}")
+        if stream_ids is not None:
+            self._chk(stream_ids, torch.int16, (self.C,), "stream_ids")
+        self._net, self._sids = net, stream_ids                      # keep them alive while attached
+        _check(lib().m17gpu_set_net_output(self._ctx, _ptr(net), _ptr(stream_ids), int(dst_override)),
+               "m17gpu_set_net_output")
+        return net
+
+    def clear_net_output(self):
+        _check(lib().m17gpu_set_net_output(self._ctx, C.c_void_p(0), C.c_void_p(0), 0), "m17gpu_set_net_output")
+        self._net = self._sids = None
+
+    def parse_lsf_batch(self, lsf):
+        """lsf: uint8 cuda tensor [n, 30] -> uint8 tensor [n, 64] of m17gpu_lsf_fields structs."""
+        import torch
+        n = int(lsf.shape[0])
+        self._chk(lsf, torch.uint8, (n, 30), "lsf")
+        out = torch.zeros((n, 64), dtype=torch.uint8, device=lsf.device)
+        _check(lib().m17gpu_parse_lsf_batch(self._ctx, _ptr(lsf), _ptr(out), n, self._stream()), "m17gpu_parse_lsf_batch")
+        return out
+
     def set_option(self, name, value):
         _check(lib().m17gpu_set_option(self._ctx, name.encode(), int(value)), "m17gpu_set_option")
 

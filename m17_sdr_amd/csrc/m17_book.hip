@@ -23,6 +23,17 @@ __device__ __forceinline__ uint32_t xor_reduce32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
 }
 
+// XOR over all 64 lanes, result wave-uniform
+__device__ __forceinline__ uint32_t xor_reduce64(uint32_t v)
+{
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 16) ^
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
 // CRC-16/M17 (m17_crc.cpp:26-35) of 30 bytes held in LDS, computed by lanes 0..29
 __device__ __forceinline__ uint32_t crc30_wave(const uint8_t *p, const uint16_t *basis, int lane)
 {
@@ -62,13 +73,7 @@ __device__ __forceinline__ uint32_t crc_var_wave(const uint8_t *p, int L, const 
 #pragma unroll
         for (int k = 0; k < 8; ++k) v ^= (b >> k & 1u) ? (uint32_t)e[k] : 0u;
     }
-    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
-    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
-    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
-    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
-    const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)v, 0) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 16) ^
-                       (uint32_t)__builtin_amdgcn_readlane((int)v, 32) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-    return r ^ (uint32_t)Z[L];
+    return xor_reduce64(v) ^ (uint32_t)Z[L];
 }
 
 struct alignas(16) LsfShared {
@@ -91,9 +96,27 @@ __device__ __forceinline__ void lsf_shared_init(LsfShared &ls, const ChanState &
 // What m17_rx_parse does to file-static state, replayed over the channel's records in event
 // order by one wave with uniform control flow (see the file header).  Records are read
 // from rsrc (HBM or an LDS copy); updated flags go to crecs.
+// cnet (optional): the channel's rows of the network sink, [rec_cap][56] bytes: every DELIVERED stream frame is
+// written there as the 54-byte M17-over-IP frame m17_net_new_rx_data builds (net_add_* m17_net.cpp:25-49, :53-74) from
+// (m_frame_id, m_lsf[1], fn, payload) AT THAT POINT of the replay -- the LSF of a later transmission in the same call
+// must not leak into earlier frames, which is why the formatter lives here and not in a pass over the finished
+// records.  One byte per lane; the CRC-16 over the first 52 bytes by GF(2) linearity like the LICH CRC.  Not mirrored:
+// the reference's 54-byte memcpy out of the 30-byte m_lsf[1] (:58).  m_frame_id = sid_base + frame_id_epoch.
 __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17gpu_rec_dev *rsrc, int n, LsfShared &ls, int lane,
-                                 const uint16_t *crc_tab)
+                                 const uint16_t *crc_tab, uint8_t *cnet = nullptr, uint32_t sid_base = 0,
+                                 unsigned long long dst_override = 0ull)
 {
+    // the lane's eight basis words of a 52-byte message (byte `lane`), and the CRC of 52 zero bytes
+    uint32_t e52[4] = {0u, 0u, 0u, 0u};
+    uint32_t z52 = 0;
+    if (cnet) {
+        z52 = crc_tab[240 + 52];
+        if (lane < 52) {
+            const uint16_t *e = crc_tab + 240 + 801 + (size_t)(51 - lane) * 8;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e52[k] = (uint32_t)e[2 * k] | ((uint32_t)e[2 * k + 1] << 16);
+        }
+    }
     uint32_t g_errors = (uint32_t)uni((int)cs.g_errors), n_frames = (uint32_t)uni((int)cs.n_frames);
     uint32_t in_frame = (uint32_t)uni((int)cs.in_frame), epoch = (uint32_t)uni((int)cs.frame_id_epoch);
     int packet_idx = uni(cs.packet_idx);
@@ -109,10 +132,11 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
     // per lane.  No memory access on the per-record path except packet payload bytes (rare).
     for (int base = 0; base < n; base += 64) {
         const int m = min(64, n - base);
-        uint32_t rw0 = 0, rw1 = 0, rd0 = 0, rd1 = 0, rd11 = 0;
+        uint32_t rw0 = 0, rw1 = 0, rd0 = 0, rd1 = 0, rd11 = 0, rp0 = 0, rp1 = 0, rp2 = 0, rp3 = 0;
         if (lane < m) {
             const uint32_t *r = reinterpret_cast<const uint32_t *>(&rsrc[base + lane]);
             rw0 = r[0]; rw1 = r[1]; rd0 = r[5]; rd1 = r[6]; rd11 = r[11];
+            if (cnet) { rp0 = r[7]; rp1 = r[8]; rp2 = r[9]; rp3 = r[10]; }            // data[8..24): the 16 payload bytes
         }
         uint32_t myflags = rw1 & 0xFFFF;
         for (int i = 0; i < m; ++i) {
@@ -142,6 +166,38 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
                     }
                 }
                 if (lsf1_ok) flags |= M17_F_DELIVERED;                      // :148
+                if (cnet && lsf1_ok) {
+                    // m17_net_new_rx_data(m_frame_id, m_lsf[1], fn, data): byte L of the frame in lane L
+                    const uint32_t pw[4] = {(uint32_t)__builtin_amdgcn_readlane((int)rp0, i), (uint32_t)__builtin_amdgcn_readlane((int)rp1, i),
+                                            (uint32_t)__builtin_amdgcn_readlane((int)rp2, i), (uint32_t)__builtin_amdgcn_readlane((int)rp3, i)};
+                    const uint32_t fnv = w1 >> 16, sid = (sid_base + epoch) & 0xFFFFu;
+                    const uint32_t lb = (uint32_t)__shfl((int)b1, (lane + 58) & 63, 64);     // m_lsf[1][L - 6]
+                    uint32_t by = 0;
+                    if (lane < 4) by = (0x2037314Du >> (8 * lane)) & 0xFFu;                 // "M17 "
+                    else if (lane == 4) by = sid >> 8;
+                    else if (lane == 5) by = sid & 0xFFu;
+                    else if (lane < 12) by = dst_override ? (uint32_t)(dst_override >> (40 - 8 * (lane - 6))) & 0xFFu : lb;
+                    else if (lane < 34) by = lb;
+                    else if (lane == 34) by = fnv >> 8;
+                    else if (lane == 35) by = fnv & 0xFFu;
+                    else if (lane < 52) {
+                        const int q = lane - 36;
+                        const uint32_t w = (q < 4) ? pw[0] : (q < 8) ? pw[1] : (q < 12) ? pw[2] : pw[3];
+                        by = (w >> (8 * (q & 3))) & 0xFFu;
+                    }
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v ^= (by >> k & 1u) ? ((e52[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) : 0u;
+                    const uint32_t crc = xor_reduce64(v) ^ z52;                                // net_add_crc, :45-49
+                    if (lane == 52) by = crc >> 8;
+                    if (lane == 53) by = crc & 0xFFu;
+                    // four lanes to a dword, rows of 56 bytes
+                    const uint32_t w4 = by | ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)by, 0x55, 0xF, 0xF, true) << 8) |
+                                        ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)by, 0xAA, 0xF, 0xF, true) << 16) |
+                                        ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)by, 0xFF, 0xF, 0xF, true) << 24);
+                    if ((lane & 3) == 0 && lane < 56)
+                        *reinterpret_cast<uint32_t *>(cnet + (size_t)(base + i) * 56 + lane) = w4;
+                }
             } else if (type == 3) {
                 // parse_packet (m17_rx_parse.cpp:34-51); data bytes live in words 5..11
                 const uint32_t d25 = ((uint32_t)__builtin_amdgcn_readlane((int)rd11, i) >> 8) & 0xFF;     // data[25]
@@ -191,7 +247,8 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
 // one wave per channel
 __global__ __launch_bounds__(64)
 void k_book_chan(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs, int rec_cap,
-                 const int32_t *__restrict__ counts, const uint16_t *__restrict__ crc_basis)
+                 const int32_t *__restrict__ counts, const uint16_t *__restrict__ crc_basis,
+                 uint8_t *__restrict__ net, const uint16_t *__restrict__ stream_ids, unsigned long long dst_override, int chan0)
 {
     __shared__ LsfShared ls;
     const int lane = lane_id(), chan = (int)blockIdx.x;
@@ -199,7 +256,69 @@ void k_book_chan(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs, 
     m17gpu_rec_dev *crecs = recs + (size_t)chan * rec_cap;
     lsf_shared_init(ls, cs, crc_basis, lane, 64);
     group_sync();
-    bookkeeping_wave(cs, crecs, crecs, min(counts[chan], rec_cap), ls, lane, crc_basis);
+    bookkeeping_wave(cs, crecs, crecs, min(counts[chan], rec_cap), ls, lane, crc_basis,
+                     net ? net + (size_t)(chan0 + chan) * rec_cap * 56 : nullptr,
+                     stream_ids ? (uint32_t)stream_ids[chan0 + chan] : 0u, dst_override);
+}
+
+// LSF field extraction for n LSFs (parse_lsf m17_rx_parse.cpp:52-70 with m17_decode_call m17_bit_utils.cpp:209-226 and
+// m17_upack_type :245-254), one thread each: the batch form of the host's m17gpu_parse_lsf, same output struct.
+struct LsfFieldsDev {                   // = m17gpu_lsf_fields (include/m17gpu.h), checked in m17gpu_capi.hip
+    uint64_t dst, src;
+    char     dst_call[10], src_call[10];
+    uint8_t  p_s, dt, et, est, can, reserved;
+    uint8_t  meta[14];
+    uint16_t crc;
+    uint8_t  crc_ok;
+};
+__device__ __forceinline__ void decode_call_dev(uint64_t word, char *call)
+{
+    if (word == 0xFFFFFFFFFFFFull) {
+        const char b[10] = {'B', 'R', 'O', 'A', 'D', 'C', 'A', 'S', 'T', 0};
+        for (int i = 0; i < 10; ++i) call[i] = b[i];
+        return;
+    }
+    for (int i = 0; i < 9; ++i) {
+        const int ch = (int)(word % 40);
+        char o = ' ';
+        if (ch >= 1 && ch <= 26) o = (char)(ch + 'A' - 1);
+        else if (ch >= 27 && ch <= 36) o = (char)(ch + '0' - 27);
+        else if (ch == 37) o = '-';
+        else if (ch == 38) o = '/';
+        else if (ch == 39) o = '.';
+        call[i] = o;
+        word /= 40;
+    }
+    call[9] = 0;
+}
+__global__ void k_parse_lsf(const uint8_t *__restrict__ lsf, LsfFieldsDev *__restrict__ out, int n)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const uint8_t *in = lsf + (size_t)i * 30;
+    uint8_t b[30];
+    for (int k = 0; k < 30; ++k) b[k] = in[k];
+    LsfFieldsDev f;
+    f.dst = 0; f.src = 0;
+    for (int k = 0; k < 6; ++k) { f.dst = (f.dst << 8) | b[k]; f.src = (f.src << 8) | b[6 + k]; }      // pack_8_to_48
+    decode_call_dev(f.dst, f.dst_call);
+    decode_call_dev(f.src, f.src_call);
+    const unsigned tw = ((unsigned)b[12] << 8) | b[13];                                                 // pack_8_to_16
+    f.reserved = (uint8_t)((tw >> 11) & 0x1F); f.can = (uint8_t)((tw >> 7) & 0xF); f.est = (uint8_t)((tw >> 5) & 0x3);
+    f.et = (uint8_t)((tw >> 3) & 0x3); f.dt = (uint8_t)((tw >> 1) & 0x3); f.p_s = (uint8_t)(tw & 1);
+    for (int k = 0; k < 14; ++k) f.meta[k] = b[14 + k];
+    f.crc = (uint16_t)(((unsigned)b[28] << 8) | b[29]);
+    uint16_t crc = 0xFFFF;                                                                              // m17_crc.cpp:26-35
+    for (int k = 0; k < 30; ++k) crc = (uint16_t)((crc << 8) ^ c_tab.crc[((crc >> 8) ^ b[k]) & 0xFF]);
+    f.crc_ok = crc == 0;
+    // whole 64-byte struct, padding zeroed
+    uint32_t w[16];
+    for (int k = 0; k < 16; ++k) w[k] = 0;
+    char *pw = reinterpret_cast<char *>(w);
+    const char *pf = reinterpret_cast<const char *>(&f);
+    for (int k = 0; k < 59; ++k) pw[k] = pf[k];
+    uint32_t *o = reinterpret_cast<uint32_t *>(out + i);
+    for (int k = 0; k < 16; ++k) o[k] = w[k];
 }
 
 } // namespace m17dev

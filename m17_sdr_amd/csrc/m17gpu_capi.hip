@@ -21,6 +21,9 @@
 #include <cstdlib>
 #include <new>
 #include <memory>
+#include <mutex>
+#include <dlfcn.h>
+#include <rccl/rccl.h>        // types and prototypes only: the library is resolved at first use, not linked
 
 using namespace m17dev;
 
@@ -36,6 +39,9 @@ struct m17gpu_ctx {
     int32_t *d_work = nullptr, *d_nwork = nullptr, *d_counts = nullptr;
     uint16_t *d_genc = nullptr, *d_gerr = nullptr, *d_crc_basis = nullptr;
     uint32_t *d_dec_hist = nullptr;          // [C][32] history of the wide-band decimator
+    uint8_t *d_net = nullptr;                // optional network sink [C][rec_cap][56] (m17gpu_set_net_output); not owned
+    const uint16_t *d_stream_ids = nullptr;  // optional [C] stream-id base per channel; not owned
+    unsigned long long dst_override = 0;     // 48-bit destination callsign written into every net frame (0 = keep the LSF's)
     int afc = 0;                             // 1 = AFC on (radio_set_afc_on): block-sequential front end
     bool profiling = false;
     int fe_impl = 0;                         // 0 = by size (four lanes per channel-block), 1 = lane per channel-block, 2 = four lanes
@@ -230,7 +236,8 @@ int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_c
                        ctx->d_genc, ctx->d_gerr, kSlotFloats, n_other);
     HIPCHK(hipGetLastError());
     if (ev_mid) HIPCHK(hipEventRecord(ev_mid, st));
-    hipLaunchKernelGGL(k_book_chan, dim3(cn), dim3(64), 0, st, ctx->d_state + c0, recs, rec_cap, cnt, ctx->d_crc_basis);
+    hipLaunchKernelGGL(k_book_chan, dim3(cn), dim3(64), 0, st, ctx->d_state + c0, recs, rec_cap, cnt, ctx->d_crc_basis,
+                       ctx->d_net, ctx->d_stream_ids, ctx->dst_override, c0);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -467,6 +474,152 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "fe_waves_per_cu")) { if (value < 0 || value > 32) return bad(); ctx->fe_waves_per_cu = value; }
     else if (!std::strcmp(name, "overlap_chunks")) { if (value < 0 || value > 16) return bad(); ctx->overlap_chunks = value; }
     else return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: unknown option ") + name);
+    return M17GPU_OK;
+}
+
+static_assert(sizeof(m17gpu_lsf_fields) == sizeof(LsfFieldsDev) && sizeof(m17gpu_lsf_fields) == 64 &&
+              offsetof(m17gpu_lsf_fields, crc_ok) == offsetof(LsfFieldsDev, crc_ok) &&
+              offsetof(m17gpu_lsf_fields, meta) == offsetof(LsfFieldsDev, meta), "LSF field layouts must agree");
+
+// Network sink of the full chain (SURVEY 8f-3 on the device): while set, every m17gpu_rx_blocks(mode 1) call writes the
+// 54-byte M17-over-IP frame of each DELIVERED record into d_net[channel][record index] (rows of 56 bytes).
+int m17gpu_set_net_output(m17gpu_ctx *ctx, uint8_t *d_net, const uint16_t *d_stream_ids, uint64_t dst_override)
+{
+    if (!ctx) return fail(M17GPU_ERR_ARG, "m17gpu_set_net_output: null context");
+    if (dst_override >> 48) return fail(M17GPU_ERR_ARG, "m17gpu_set_net_output: dst_override is a 48-bit callsign");
+    ctx->d_net = d_net; ctx->d_stream_ids = d_net ? d_stream_ids : nullptr; ctx->dst_override = dst_override;
+    return M17GPU_OK;
+}
+
+int m17gpu_parse_lsf_batch(m17gpu_ctx *ctx, const uint8_t *d_lsf, m17gpu_lsf_fields *d_out, int n, void *stream)
+{
+    if (!ctx || !d_lsf || !d_out || n <= 0) return fail(M17GPU_ERR_ARG, "m17gpu_parse_lsf_batch: bad argument");
+    ON_CTX_DEVICE(ctx);
+    hipLaunchKernelGGL(k_parse_lsf, dim3(cdiv(n, 128)), dim3(128), 0, S(stream), d_lsf, reinterpret_cast<LsfFieldsDev *>(d_out), n);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-GPU fan-out for a C / C++ host: the path shards by channel with no data-path collective; the only
+// exchanges are the IQ fan-out from an ingest rank and the gather of the 64-byte records, both point to point.  RCCL
+// is taken from the process (the copy the host application or PyTorch already loaded, else librccl.so.1) at first
+// use: the library itself does not link it, so single-GPU users need no RCCL at all.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+const RcclApi &rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        for (const char *name : {"librccl.so", "librccl.so.1"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);                 // whichever RCCL the process already runs on
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(h, "ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        api.Send = reinterpret_cast<decltype(api.Send)>(dlsym(h, "ncclSend"));
+        api.Recv = reinterpret_cast<decltype(api.Recv)>(dlsym(h, "ncclRecv"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        api.ok = api.GroupStart && api.GroupEnd && api.Send && api.Recv;
+    });
+    return api;
+}
+#define RCCLCHK(expr)                                                                                    \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess)                                                                           \
+            return fail(M17GPU_ERR_HIP, std::string(#expr) + ": " + (R.GetErrorString ? R.GetErrorString(r_) : "RCCL error")); \
+    } while (0)
+} // namespace
+
+void m17gpu_shard_range(int rank, int world, int n_channels, int *lo, int *hi)
+{
+    const int base = n_channels / world, extra = n_channels % world;
+    const int a = rank * base + (rank < extra ? rank : extra);
+    if (lo) *lo = a;
+    if (hi) *hi = a + base + (rank < extra ? 1 : 0);
+}
+
+int m17gpu_shard_scatter_iq(m17gpu_ctx *ctx, void *comm, int rank, int world, int src_rank,
+                            const int16_t *d_iq_all, int n_channels_total, int nblk, int16_t *d_iq_mine, void *stream)
+{
+    if (!ctx || !comm || world <= 0 || rank < 0 || rank >= world || src_rank < 0 || src_rank >= world || nblk <= 0 ||
+        n_channels_total <= 0 || !d_iq_mine || (rank == src_rank && !d_iq_all))
+        return fail(M17GPU_ERR_ARG, "m17gpu_shard_scatter_iq: bad argument");
+    int lo, hi;
+    m17gpu_shard_range(rank, world, n_channels_total, &lo, &hi);
+    if (hi - lo != ctx->C) return fail(M17GPU_ERR_ARG, "m17gpu_shard_scatter_iq: the context does not hold this rank's channel range");
+    const RcclApi &R = rccl();
+    if (!R.ok) return fail(M17GPU_ERR_HIP, "m17gpu_shard_scatter_iq: no RCCL library in this process (librccl.so.1)");
+    ON_CTX_DEVICE(ctx);
+    const size_t per = (size_t)nblk * kBlockSamples * 2 * sizeof(int16_t);       // bytes per channel
+    hipStream_t st = S(stream);
+    // one group: the sends to all peers are in flight together, each on its own xGMI link (a ring would be per-link bound)
+    RCCLCHK(R.GroupStart());
+    if (rank == src_rank) {
+        for (int r = 0; r < world; ++r) {
+            int a, b;
+            m17gpu_shard_range(r, world, n_channels_total, &a, &b);
+            if (r == src_rank || b <= a) continue;
+            RCCLCHK(R.Send(reinterpret_cast<const char *>(d_iq_all) + (size_t)a * per, (size_t)(b - a) * per, ncclChar, r,
+                           static_cast<ncclComm_t>(comm), st));
+        }
+    } else if (hi > lo) {
+        RCCLCHK(R.Recv(d_iq_mine, (size_t)(hi - lo) * per, ncclChar, src_rank, static_cast<ncclComm_t>(comm), st));
+    }
+    RCCLCHK(R.GroupEnd());
+    if (rank == src_rank && hi > lo)
+        HIPCHK(hipMemcpyAsync(d_iq_mine, reinterpret_cast<const char *>(d_iq_all) + (size_t)lo * per, (size_t)(hi - lo) * per,
+                              hipMemcpyDeviceToDevice, st));
+    return M17GPU_OK;
+}
+
+int m17gpu_shard_gather_records(m17gpu_ctx *ctx, void *comm, int rank, int world, int dst_rank,
+                                const m17gpu_rec *d_recs_mine, const int32_t *d_counts_mine, int rec_cap,
+                                int n_channels_total, m17gpu_rec *d_recs_all, int32_t *d_counts_all, void *stream)
+{
+    if (!ctx || !comm || world <= 0 || rank < 0 || rank >= world || dst_rank < 0 || dst_rank >= world || rec_cap <= 0 ||
+        n_channels_total <= 0 || !d_recs_mine || !d_counts_mine || (rank == dst_rank && (!d_recs_all || !d_counts_all)))
+        return fail(M17GPU_ERR_ARG, "m17gpu_shard_gather_records: bad argument");
+    int lo, hi;
+    m17gpu_shard_range(rank, world, n_channels_total, &lo, &hi);
+    if (hi - lo != ctx->C) return fail(M17GPU_ERR_ARG, "m17gpu_shard_gather_records: the context does not hold this rank's channel range");
+    const RcclApi &R = rccl();
+    if (!R.ok) return fail(M17GPU_ERR_HIP, "m17gpu_shard_gather_records: no RCCL library in this process (librccl.so.1)");
+    ON_CTX_DEVICE(ctx);
+    const size_t per = (size_t)rec_cap * sizeof(m17gpu_rec);
+    hipStream_t st = S(stream);
+    RCCLCHK(R.GroupStart());
+    if (rank == dst_rank) {
+        for (int r = 0; r < world; ++r) {
+            int a, b;
+            m17gpu_shard_range(r, world, n_channels_total, &a, &b);
+            if (r == dst_rank || b <= a) continue;
+            RCCLCHK(R.Recv(reinterpret_cast<char *>(d_recs_all) + (size_t)a * per, (size_t)(b - a) * per, ncclChar, r,
+                           static_cast<ncclComm_t>(comm), st));
+            RCCLCHK(R.Recv(d_counts_all + a, (size_t)(b - a), ncclInt32, r, static_cast<ncclComm_t>(comm), st));
+        }
+    } else if (hi > lo) {
+        RCCLCHK(R.Send(d_recs_mine, (size_t)(hi - lo) * per, ncclChar, dst_rank, static_cast<ncclComm_t>(comm), st));
+        RCCLCHK(R.Send(d_counts_mine, (size_t)(hi - lo), ncclInt32, dst_rank, static_cast<ncclComm_t>(comm), st));
+    }
+    RCCLCHK(R.GroupEnd());
+    if (rank == dst_rank && hi > lo) {
+        HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(d_recs_all) + (size_t)lo * per, d_recs_mine, (size_t)(hi - lo) * per,
+                              hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_counts_all + lo, d_counts_mine, (size_t)(hi - lo) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    }
     return M17GPU_OK;
 }
 

@@ -644,6 +644,29 @@ static int parse_packet(m17o_chan *st, const uint8_t *data, uint8_t eof, uint8_t
     return valid;
 }
 
+/* The network sink of decode_stream_frame (m17_rx_parse.cpp:151-154): m17_net_new_rx_data(m_frame_id, m_lsf[1], fn,
+ * data) builds the 54-byte M17-over-IP frame "M17 " | stream id | LSF bytes 0..27 | FN | 16 payload bytes | CRC-16 of
+ * the first 52 bytes (net_add_* m17_net.cpp:25-49, :53-74; the destination callsign optionally overwritten as :60-62
+ * does with the reflector's).  Not mirrored: the reference copies 54 bytes out of the 30-byte m_lsf[1] (:58), of which
+ * only the first 28 reach the frame.  m_frame_id is rand() there; here it is stream_id_base + frame_id_epoch, the
+ * event counter that replaces it.  The batch driver below points the sink at the channel's rows. */
+typedef struct { uint8_t *net; const m17o_rec *recs; int cap; uint16_t sid_base; uint64_t dst_override; } net_sink;
+static __thread net_sink t_sink;
+
+void m17o_format_net_frame(uint16_t stream_id, const uint8_t *lsf, uint16_t fn, const uint8_t *pld,
+                           uint64_t dst_override, uint8_t *out)
+{
+    out[0] = 0x4D; out[1] = 0x31; out[2] = 0x37; out[3] = 0x20;
+    out[4] = (uint8_t)(stream_id >> 8); out[5] = (uint8_t)(stream_id & 0xFF);
+    memcpy(&out[6], lsf, 28);
+    if (dst_override)
+        for (int i = 0; i < 6; i++) out[6 + i] = (uint8_t)(dst_override >> (40 - 8 * i));     /* pack_48_to_8 */
+    out[34] = (uint8_t)(fn >> 8); out[35] = (uint8_t)(fn & 0xFF);
+    memcpy(&out[36], pld, 16);
+    uint16_t crc = m17o_crc(out, 52);
+    out[52] = (uint8_t)(crc >> 8); out[53] = (uint8_t)(crc & 0xFF);
+}
+
 /* m17_rx_parse.cpp:185-226 and the three decoders :86-177 */
 void m17o_rx_parse(m17o_chan *st, const float *s, uint8_t type, m17o_rec *r)
 {
@@ -684,7 +707,12 @@ void m17o_rx_parse(m17o_chan *st, const float *s, uint8_t type, m17o_rec *r)
         m17o_viterbi_decode(so1, bits, 296);
         m17o_pack_1_to_8(&bits[1], &r->data[6], 144);
         r->fn = (uint16_t)((r->data[6] << 8) | r->data[7]);
-        if (m17o_crc(st->m_lsf[1], 30) == 0) r->flags |= M17O_F_DELIVERED;
+        if (m17o_crc(st->m_lsf[1], 30) == 0) {
+            r->flags |= M17O_F_DELIVERED;
+            if (t_sink.net && r >= t_sink.recs && r < t_sink.recs + t_sink.cap)
+                m17o_format_net_frame((uint16_t)(t_sink.sid_base + st->frame_id_epoch), st->m_lsf[1], r->fn, &r->data[8],
+                                      t_sink.dst_override, t_sink.net + (size_t)(r - t_sink.recs) * 56);
+        }
         break; }
     case 3: {                                       /* decode_packet_frame :161-177 */
         m17o_demap_frame(s, sb);
@@ -848,9 +876,10 @@ void m17o_pluto_decimate(int16_t *hist, const int16_t *in, int n_in, int16_t *ou
     }
 }
 
-int m17o_rx_blocks(m17o_chan *st, int C, int nblk, const int16_t *iq,
-                   m17o_rec *recs, int cap, int32_t *counts,
-                   float *syms, int32_t *nsyms, int mode, int nthreads)
+int m17o_rx_blocks_net(m17o_chan *st, int C, int nblk, const int16_t *iq,
+                       m17o_rec *recs, int cap, int32_t *counts,
+                       float *syms, int32_t *nsyms, int mode, int nthreads,
+                       uint8_t *net, const uint16_t *stream_ids, uint64_t dst_override)
 {
     const size_t blk = (size_t)M17O_BLOCK_SAMPLES * 2;
     const size_t symstride = (size_t)nblk * 193 + 8;
@@ -858,6 +887,11 @@ int m17o_rx_blocks(m17o_chan *st, int C, int nblk, const int16_t *iq,
 #pragma omp parallel for schedule(static) num_threads(nthreads)
     for (int c = 0; c < C; c++) {
         int n = 0, ns = 0;
+        t_sink.net = (net && recs) ? net + (size_t)c * cap * 56 : NULL;
+        t_sink.recs = recs ? recs + (size_t)c * cap : NULL;
+        t_sink.cap = cap;
+        t_sink.sid_base = stream_ids ? stream_ids[c] : 0;
+        t_sink.dst_override = dst_override;
         for (int b = 0; b < nblk; b++) {
             int k = 0;
             int at = n < cap ? n : cap;
@@ -868,7 +902,15 @@ int m17o_rx_blocks(m17o_chan *st, int C, int nblk, const int16_t *iq,
             if (nsyms) nsyms[(size_t)c * nblk + b] = k;
             ns += k;
         }
+        t_sink.net = NULL;
         if (counts) counts[c] = n;
     }
     return 0;
+}
+
+int m17o_rx_blocks(m17o_chan *st, int C, int nblk, const int16_t *iq,
+                   m17o_rec *recs, int cap, int32_t *counts,
+                   float *syms, int32_t *nsyms, int mode, int nthreads)
+{
+    return m17o_rx_blocks_net(st, C, nblk, iq, recs, cap, counts, syms, nsyms, mode, nthreads, NULL, NULL, 0);
 }

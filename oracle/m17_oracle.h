@@ -141,6 +141,13 @@ int  m17o_dsp_rx(m17o_chan *st, const int16_t *iq, m17o_rec *recs, int cap,
  * iq: [C][nblk][1920][2]; recs: [C][cap]; counts: [C]; syms: per channel a
  * contiguous symbol stream [C][nblk*193+8] or NULL; nsyms: per-block symbol
  * counts [C][nblk] or NULL; mode 0 = front end only (a2 without parse), 1 = full chain */
+/* the same with the network sink of decode_stream_frame attached (m17_net_new_rx_data, m17_net.cpp:25-74): net
+ * [C][cap][56] receives the 54-byte M17-over-IP frame of every DELIVERED record at that record's index */
+int  m17o_rx_blocks_net(m17o_chan *st, int C, int nblk, const int16_t *iq, m17o_rec *recs, int cap, int32_t *counts,
+                        float *syms, int32_t *nsyms, int mode, int nthreads,
+                        uint8_t *net, const uint16_t *stream_ids, uint64_t dst_override);
+void m17o_format_net_frame(uint16_t stream_id, const uint8_t *lsf, uint16_t fn, const uint8_t *pld,
+                           uint64_t dst_override, uint8_t *out);
 int  m17o_rx_blocks(m17o_chan *st, int C, int nblk, const int16_t *iq,
                     m17o_rec *recs, int cap, int32_t *counts,
                     float *syms, int32_t *nsyms, int mode, int nthreads);

@@ -61,8 +61,9 @@ class Channels:
         for c in range(n):
             L().m17o_chan_reset(vp(self.buf[c]))
 
-    def rx_blocks(self, iq, mode=1, cap=None, want_syms=True, nthreads=8):
-        """iq int16 [C, nblk, 1920, 2] -> dict(recs[C,cap], counts[C], syms, nsyms)."""
+    def rx_blocks(self, iq, mode=1, cap=None, want_syms=True, nthreads=8, net=False, stream_ids=None, dst_override=0):
+        """iq int16 [C, nblk, 1920, 2] -> dict(recs[C,cap], counts[C], syms, nsyms[, net[C,cap,56]]).
+        net=True attaches the network sink of decode_stream_frame (m17_net_new_rx_data, m17_net.cpp:53-74)."""
         Cn, nblk = iq.shape[0], iq.shape[1]
         assert Cn == self.n and iq.dtype == np.int16 and iq.flags.c_contiguous
         cap = cap or (2 * nblk + 2)
@@ -70,10 +71,13 @@ class Channels:
         counts = np.zeros((Cn,), np.int32)
         syms = np.zeros((Cn, nblk * 193 + 8), np.float32) if want_syms else None
         nsyms = np.zeros((Cn, nblk), np.int32) if want_syms else None
-        L().m17o_rx_blocks(vp(self.buf), Cn, nblk, vp(iq), vp(recs), cap, vp(counts),
-                           vp(syms) if want_syms else None, vp(nsyms) if want_syms else None,
-                           int(mode), int(nthreads))
-        return {"recs": recs, "counts": counts, "syms": syms, "nsyms": nsyms}
+        netbuf = np.zeros((Cn, cap, 56), np.uint8) if net else None
+        sids = np.ascontiguousarray(stream_ids, np.uint16) if stream_ids is not None else None
+        L().m17o_rx_blocks_net(vp(self.buf), Cn, nblk, vp(iq), vp(recs), cap, vp(counts),
+                               vp(syms) if want_syms else None, vp(nsyms) if want_syms else None,
+                               int(mode), int(nthreads), vp(netbuf) if net else None,
+                               vp(sids) if sids is not None else None, C.c_uint64(int(dst_override)))
+        return {"recs": recs, "counts": counts, "syms": syms, "nsyms": nsyms, "net": netbuf}
 
     def set_afc(self, on=True):
         for c in range(self.n):

@@ -79,6 +79,59 @@ def test_scatter_and_gather_with_device_tensors_over_rccl():
         dist.destroy_process_group()
 
 
+def test_capi_fanout_entries_with_a_one_rank_rccl_communicator():
+    """m17gpu_shard_scatter_iq / m17gpu_shard_gather_records (include/m17gpu.h), the C-ABI a C++ host drives the
+    8-GPU loop with: an ncclComm_t made here through RCCL's C API (one rank -- one device is all a test box has), the
+    two calls on a stream around m17gpu_rx_blocks, result against the oracle.  With one rank the group is empty and
+    the shard moves device to device; range arithmetic is checked for 8 ranks against shard.channel_range."""
+    import ctypes as C
+    import torch
+    import m17_sdr_amd as m
+    from m17_sdr_amd.shard import channel_range
+    lib = m.lib()
+    for world, total in ((8, 131072), (8, 1003), (3, 7), (5, 3)):
+        for r in range(world):
+            lo, hi = C.c_int(), C.c_int()
+            lib.m17gpu_shard_range(r, world, total, C.byref(lo), C.byref(hi))
+            assert (lo.value, hi.value) == channel_range(r, world, total)
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UID(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid, comm = UID(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    torch.zeros(1, device="cuda:0")
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        Cn, nblk = 37, 6
+        sig = m.generate_batch(Cn, nblk, n_stream_frames=4)
+        full = torch.from_numpy(sig["iq"]).cuda()
+        mine = torch.empty_like(full)
+        rx = m.Receiver(Cn, nblk)
+        st = C.c_void_p(torch.cuda.current_stream(0).cuda_stream)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = lib.m17gpu_shard_scatter_iq(rx._ctx, comm, 0, 1, 0, p(full), Cn, nblk, p(mine), st)
+        assert rc == 0, lib.m17gpu_last_error()
+        out = rx.rx_blocks(mine, 1, rx.alloc_outputs(nblk))
+        allr, allc = torch.zeros_like(out["recs"]), torch.zeros_like(out["counts"])
+        rc = lib.m17gpu_shard_gather_records(rx._ctx, comm, 0, 1, 0, p(out["recs"]), p(out["counts"]), out["rec_cap"],
+                                             Cn, p(allr), p(allc), st)
+        assert rc == 0, lib.m17gpu_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(mine, full)
+        ref = oracle.Channels(Cn).rx_blocks(sig["iq"], mode=1, want_syms=False)
+        np.testing.assert_array_equal(allc.cpu().numpy(), ref["counts"])
+        recs = allr.cpu().numpy().view(oracle.REC_DTYPE).reshape(Cn, -1)
+        for c in range(Cn):
+            assert recs[c, :ref["counts"][c]].tobytes() == ref["recs"][c, :ref["counts"][c]].tobytes()
+        # a context that does not hold the rank's range is refused
+        assert lib.m17gpu_shard_scatter_iq(rx._ctx, comm, 0, 2, 0, p(full), Cn, nblk, p(mine), st) != 0
+        rx.close()
+    finally:
+        rccl.ncclCommDestroy(comm)
+
+
 def test_two_receivers_do_not_depend_on_the_current_device():
     """Every C-ABI entry selects its context's device itself (and restores the caller's); the Python handle takes
     the stream of ITS device.  With one GPU the check is that a foreign 'current device' request is harmless and

@@ -725,3 +725,74 @@ def test_afc_loop_tolerance_parity_on_frequency_offsets():
     rx.close()
     # and the same signal WITHOUT AFC still matches the oracle bit for bit (default path untouched)
     _ = _compare_raw(np.ascontiguousarray(shifted[:, :nblk]), mode=1)
+
+
+def test_net_frames_on_device_match_the_reference_sink():
+    """SURVEY 8f-3 on the device: with the network sink attached, the bookkeeping kernel writes the 54-byte
+    M17-over-IP frame of every DELIVERED stream frame (net_add_* m17_net.cpp:25-49 as called from
+    m17_net_new_rx_data :53-74 <- decode_stream_frame m17_rx_parse.cpp:151-154) -- built from m_lsf[1] as it stood
+    at that frame.  Two consecutive calls over a stream of several transmissions per channel; every frame against the oracle's restatement of that sink, plus the frame's own CRC and fields."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    Cn, nblk, calls = 96, 20, 2
+    sig = m.generate_batch(Cn, nblk * calls, n_stream_frames=9, ebn0_db=200.0)
+    call = m.lib().m17gen_encode_call(b"M17-M17 A")
+    sids = (np.arange(Cn) * 257 + 11).astype(np.uint16)
+    rx = m.Receiver(Cn, nblk)
+    net = rx.set_net_output(stream_ids=torch.from_numpy(sids.view(np.int16)).cuda(), dst_override=call)
+    och = oracle.Channels(Cn)
+    frames = 0
+    for k in range(calls):
+        part = np.ascontiguousarray(sig["iq"][:, k * nblk:(k + 1) * nblk])
+        net.zero_()
+        out = rx.rx_blocks(torch.from_numpy(part).cuda(), 1, rx.alloc_outputs(nblk))
+        torch.cuda.synchronize()
+        ref = och.rx_blocks(part, mode=1, want_syms=False, net=True, stream_ids=sids, dst_override=call)
+        counts = out["counts"].cpu().numpy()
+        np.testing.assert_array_equal(counts, ref["counts"])
+        recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(Cn, -1)
+        g = net.cpu().numpy()
+        cap = recs.shape[1]
+        valid = np.arange(cap)[None, :] < counts[:, None]
+        deliv = valid & ((recs["flags"] & m.F_DELIVERED) != 0)
+        assert np.array_equal(g[deliv][:, :54], ref["net"][deliv][:, :54])
+        assert not g[~deliv].any()                                   # rows of other records stay untouched
+        for c, i in zip(*np.nonzero(deliv)):
+            f = g[c, i, :54]
+            assert bytes(f[:4]) == b"M17 " and oracle.L().m17o_crc(bytes(f), 54) == 0
+            assert int.from_bytes(bytes(f[6:12]), "big") == call
+            assert (int(f[34]) << 8 | int(f[35])) == recs[c, i]["fn"] and bytes(f[36:52]) == bytes(recs[c, i]["data"][8:24])
+        frames += int(deliv.sum())
+    assert frames > Cn * 8, frames
+    rx.clear_net_output()
+    rx.close()
+
+
+def test_parse_lsf_batch_matches_host_parser():
+    """m17gpu_parse_lsf_batch (parse_lsf m17_rx_parse.cpp:52-70, m17_decode_call m17_bit_utils.cpp:209-226,
+    m17_upack_type :245-254) on the device against the host parser, struct for struct: transmitted LSFs, the
+    survey's callsign KATs, the broadcast address, random bytes (CRC bad)."""
+    import ctypes as C
+    torch = _torch()
+    import m17_sdr_amd as m
+    L = m.lib()
+    rng = np.random.default_rng(3)
+    sig = m.generate_batch(40, 2, n_stream_frames=1)
+    lsf = [sig["lsf"][c] for c in range(40)]
+    for dst, src in ((0xFFFFFFFFFFFF, 0x00102C8DA29F), (0x0000009FDD51, 0x00102C8DA29F), (0, 40 ** 9 - 1)):
+        b = np.zeros(30, np.uint8)
+        L.m17gen_build_lsf(C.c_uint64(dst), C.c_uint64(src), (5 << 7) | (1 << 1) | 1, oracle.vp(np.arange(14, dtype=np.uint8)), oracle.vp(b))
+        lsf.append(b)
+    lsf += [rng.integers(0, 256, 30).astype(np.uint8) for _ in range(200)]
+    lsf = np.ascontiguousarray(np.stack(lsf))
+    rx = m.Receiver(1, 1)
+    got = rx.parse_lsf_batch(torch.from_numpy(lsf).cuda()).cpu().numpy()
+    want = np.zeros((len(lsf), 64), np.uint8)
+    for i in range(len(lsf)):
+        assert L.m17gpu_parse_lsf(oracle.vp(lsf[i]), oracle.vp(want[i])) == 0
+    np.testing.assert_array_equal(got, want)
+    assert want[:43, 58].all() and not want[43:, 58].all()          # crc_ok of built LSFs; random ones fail
+    buf = C.create_string_buffer(10)
+    oracle.L().m17o_decode_call(C.c_uint64(0x00102C8DA29F), buf)
+    assert bytes(got[40, 26:35]) == buf.value == b"G4GUO/P  "       # src_call of the first KAT row
+    rx.close()
