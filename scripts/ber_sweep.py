@@ -32,70 +32,97 @@ def measure(recs, counts, sig, m):
     return bit_err, bits, frames, int(sig["nframes"].sum())
 
 
+def lock_stats(recs, counts, m):
+    """What the framer did: lock events, losses, and how many channels ever locked."""
+    cap = recs.shape[1]
+    valid = np.arange(cap)[None, :] < np.minimum(counts, cap)[:, None]
+    fl = recs["flags"]
+    aos = valid & ((fl & m.F_AOS) != 0)
+    lost = valid & ((fl & m.F_LOST) != 0)
+    eot = valid & ((fl & m.F_EOT) != 0)
+    parsed = valid & ((fl & m.F_PARSED) != 0)
+    return {"aos": int(aos.sum()), "lost": int(lost.sum()), "eot": int(eot.sum()), "parsed_any_type": int(parsed.sum()),
+            "channels_locked_ever": int(aos.any(axis=1).sum()),
+            "first_lock_block_mean": float(np.where(aos.any(axis=1), recs["block"][np.arange(recs.shape[0]), aos.argmax(axis=1)], 0)[aos.any(axis=1)].mean())
+            if aos.any() else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--channels", type=int, default=16384)
     ap.add_argument("--blocks", type=int, default=30)
-    ap.add_argument("--chunk", type=int, default=2048, help="channels generated / processed per pass")
-    ap.add_argument("--ebn0", type=float, nargs="*", default=[float(x) for x in range(0, 11)])
-    ap.add_argument("--oracle-channels", type=int, default=-1, help="channels per point also run through the CPU oracle (-1 = all)")
+    ap.add_argument("--ebn0", type=float, nargs="*", default=[float(x) for x in range(0, 21, 1)] + [200.0])
+    ap.add_argument("--min-bits", type=float, default=1e6, help="payload bits wanted per point with FER < 0.99 (SURVEY 8d)")
+    ap.add_argument("--max-passes", type=int, default=8, help="passes of --channels fresh channels per point at most")
     ap.add_argument("--noise-cutoff", type=float, default=6250.0, help="one-sided channel-filter cutoff applied to the noise, Hz (0 = white over 48 kHz)")
-    ap.add_argument("--gen", choices=["gpu", "host"], default="gpu", help="signal source (SURVEY 8f-1 device generator, or the host one)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
-    if a.oracle_channels < 0:
-        a.oracle_channels = a.channels
-    if a.gen == "gpu":
-        a.chunk = a.channels                      # the whole config in one launch, as BASELINE config #4 words it
     import torch
     import m17_sdr_amd as m
     from tests import oracle
     rows = []
+    n = a.channels
     for eb in a.ebn0:
         t0 = time.time()
         tot = dict(bit_err=0, bits=0, frames=0, sent=0, identical=True, checked=0)
-        for c0 in range(0, a.channels, a.chunk):
-            n = min(a.chunk, a.channels - c0)
+        lk = None
+        passes = 0
+        while passes < a.max_passes:
             rx = m.Receiver(n, a.blocks)
-            if a.gen == "gpu":
-                dsig = rx.gen_batch(a.blocks, n_stream_frames=a.blocks - 6, ebn0_db=eb, first_channel=c0,
-                                    noise_cutoff_hz=a.noise_cutoff)
-                iq_dev = dsig["iq"]
-                k0 = min(n, a.oracle_channels)
-                sig = {"payload": dsig["payload"].cpu().numpy(), "nframes": dsig["nframes"].cpu().numpy(),
-                       "iq": iq_dev[:k0].cpu().numpy()}
-            else:
-                sig = m.generate_batch(n, a.blocks, n_stream_frames=a.blocks - 6, ebn0_db=eb, first_channel=c0, nthreads=16,
-                                       noise_cutoff_hz=a.noise_cutoff)
-                iq_dev = torch.from_numpy(sig["iq"]).cuda()
-            out = rx.rx_blocks(iq_dev, 1, rx.alloc_outputs(a.blocks))
+            # fresh channels every pass: seeds continue where the last pass stopped
+            dsig = rx.gen_batch(a.blocks, n_stream_frames=a.blocks - 6, ebn0_db=eb, first_channel=passes * n,
+                                noise_cutoff_hz=a.noise_cutoff)
+            sig = {"payload": dsig["payload"].cpu().numpy(), "nframes": dsig["nframes"].cpu().numpy(),
+                   "iq": dsig["iq"].cpu().numpy()}
+            out = rx.rx_blocks(dsig["iq"], 1, rx.alloc_outputs(a.blocks))
             torch.cuda.synchronize()
             recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(n, -1)
             counts = out["counts"].cpu().numpy()
-            be, b, f, s = measure(recs, counts, sig, m)
-            tot["bit_err"] += be; tot["bits"] += b; tot["frames"] += f; tot["sent"] += s
-            k = min(n, sig["iq"].shape[0], max(0, a.oracle_channels - tot["checked"]))
-            if k:
-                ref = oracle.Channels(k).rx_blocks(np.ascontiguousarray(sig["iq"][:k]), mode=1, want_syms=False, nthreads=16)
-                same = np.array_equal(ref["counts"], counts[:k]) and all(
-                    ref["recs"][c, :counts[c]].tobytes() == recs[c, :counts[c]].tobytes() for c in range(k))
-                tot["identical"] = tot["identical"] and bool(same)
-                tot["checked"] += k
+            be, b, f, s_ = measure(recs, counts, sig, m)
+            tot["bit_err"] += be; tot["bits"] += b; tot["frames"] += f; tot["sent"] += s_
+            st = lock_stats(recs, counts, m)
+            lk = st if lk is None else {k: (lk[k] + st[k] if isinstance(st[k], int) else st[k]) for k in st}
+            # EVERY channel of every pass also goes through the CPU oracle
+            ref = oracle.Channels(n).rx_blocks(sig["iq"], mode=1, want_syms=False, nthreads=16)
+            same = np.array_equal(ref["counts"], counts) and all(
+                ref["recs"][c, :counts[c]].tobytes() == recs[c, :counts[c]].tobytes() for c in range(n))
+            tot["identical"] = tot["identical"] and bool(same)
+            tot["checked"] += n
             rx.close()
-        row = {"ebn0_db": eb, "ebn0_info_bit_db": round(eb + 10 * np.log10(272 / 144), 2), "payload_bits": tot["bits"], "bit_errors": tot["bit_err"],
+            passes += 1
+            fer = 1.0 - tot["frames"] / max(1, tot["sent"])
+            if tot["bits"] >= a.min_bits or fer >= 0.99:
+                break
+        fer = 1.0 - tot["frames"] / max(1, tot["sent"])
+        row = {"ebn0_db": eb if eb < 100 else "noiseless", "ebn0_info_bit_db": round(eb + 10 * np.log10(272 / 144), 2) if eb < 100 else None,
+               "passes": passes, "channels_total": passes * n,
+               "payload_bits": tot["bits"], "bit_errors": tot["bit_err"],
+               "status": "no_lock" if tot["frames"] == 0 else ("ok" if tot["bits"] >= a.min_bits else "few_frames (FER >= 0.99: no further passes)"),
                "ber": (tot["bit_err"] / tot["bits"]) if tot["bits"] else None,
-               "frames_decoded": tot["frames"], "frames_sent": tot["sent"],
-               "fer": 1.0 - tot["frames"] / max(1, tot["sent"]),
+               "frames_decoded": tot["frames"], "frames_sent": tot["sent"], "fer": fer,
+               "framer": lk,
                "oracle_channels_compared": tot["checked"], "gpu_equals_oracle": tot["identical"],
                "seconds": round(time.time() - t0, 1)}
         rows.append(row)
         print(json.dumps(row), flush=True)
     if a.out:
-        json.dump({"channels": a.channels, "blocks": a.blocks, "noise_cutoff_hz": a.noise_cutoff, "signal_source": a.gen,
+        json.dump({"channels": a.channels, "blocks": a.blocks, "noise_cutoff_hz": a.noise_cutoff, "signal_source": "gpu",
                    "axis": "ebn0_db = energy per CHANNEL bit / N0 = Es/N0 - 3.01 dB (2 channel bits per 4-FSK symbol; Es = A^2 x 10 "
                            "samples; N0 = complex noise variance per 48 kHz sample before the 12.5 kHz channel filter); "
                            "ebn0_info_bit_db adds the code-rate term of SURVEY 8(d), R = 144/272 (P2-punctured K=5): +2.76 dB",
-                   "oracle": "every channel of every point also decoded by the CPU oracle; gpu_equals_oracle = all records identical",
+                   "oracle": "every channel of every pass also decoded by the CPU oracle; gpu_equals_oracle = all records identical",
+                   "sizing": f"passes of {a.channels} fresh channels x {a.blocks} blocks are added until a point holds {a.min_bits:.0e} payload bits, "
+                             f"its FER is >= 0.99, or {a.max_passes} passes are done; status no_lock = not one stream frame was parsed",
+                   "why_few_frames_at_low_ebn0": "FER counts every transmitted stream frame.  The reference's framer locks only on an 8-symbol "
+                       "window with NO sign error against a sync template and an amplitude spread (max|v|-min|v|)/max|v| below 0.3 "
+                       "(m17_unlocked_sync_check, m17_rx_frame.cpp:82-92), after the timing loop has settled at threshold 10; at 8 dB "
+                       "band-limited noise most channels never pass that test during the 24 transmitted frames (framer.channels_locked_ever) "
+                       "and a channel that locks late has lost the frames before (framer.first_lock_block_mean); frames inside a held lock "
+                       "decode with the BER shown.  The noiseless point is the reference's own start-up loss: carrier, two preambles and "
+                       "the link setup frame pass before the first stream frame can complete, and delivery waits for a CRC-good LICH.",
+                   "noiseless_residual": "the noiseless point's BER is not zero: the reference's framer now and then classifies the EOT / "
+                       "carrier transition as one more stream frame (frame number below the count sent, payload garbage); GPU and oracle "
+                       "agree on every such record",
                    "points": rows}, open(a.out, "w"), indent=1)
 
 
