@@ -99,7 +99,6 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
 #endif
     if (!is_framer) {
         // =========================== timing wave ===========================
-        const unsigned long long incl = (gl == 63) ? ~0ull : ((2ull << gl) - 1ull);
         int clk = cs.clk, thr = cs.thr, index = cs.index;
         float sum = cs.sum, dif = cs.dif;
         int known_lock = cs.flock;
@@ -166,19 +165,30 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                     const float s = a.x, d = a.y;
                     const bool vote_ok = (gl < nv) && (p + 2 * gl + 1 < kDiscOut);
                     const float dd = (s < 0.0f) ? -d : d;
-                    const unsigned long long um = __builtin_amdgcn_ballot_w64(vote_ok && dd > 0.0f);
-                    const unsigned long long dm = __builtin_amdgcn_ballot_w64(vote_ok && dd < 0.0f);
-                    const int tk = thr + (int)__popcll(um & incl) - (int)__popcll(dm & incl);
-                    const unsigned long long cr = __builtin_amdgcn_ballot_w64(vote_ok && (tk > thresh || tk < -thresh));
-                    const int kl = cr ? (int)__ffsll((long long)cr) - 1 : 0;
-                    const int naccept = cr ? kl + 1 : nv;
+                    const bool up = vote_ok && dd > 0.0f, dn = vote_ok && dd < 0.0f;
+                    const unsigned long long um = __builtin_amdgcn_ballot_w64(up);
+                    const unsigned long long dm = __builtin_amdgcn_ballot_w64(dn);
+                    const int nu = (int)__popcll(um), nd = (int)__popcll(dm);
+                    int naccept = nv, kl = -1, ts = 0;
+                    // the counter can only leave [-thresh, thresh] in this round if all the votes of one sign could
+                    // carry it there: otherwise the round is accepted whole on two scalar compares (k_sync_frame_wave)
+                    if (uni(thr) + nu > thresh || uni(thr) - nd < -thresh) {
+                        const int pu = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+                        const int pd = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0u));
+                        const int tk = thr + pu - pd + (int)up - (int)dn;
+                        const unsigned long long cr = __builtin_amdgcn_ballot_w64(vote_ok && (tk > thresh || tk < -thresh));
+                        if (cr) {
+                            kl = (int)__builtin_ctzll(cr);
+                            naccept = kl + 1;
+                            ts = __builtin_amdgcn_readlane(tk, kl);
+                        }
+                    }
                     if (gl < naccept && (m_idx + gl) >= 0) my.H[(hp + m_idx + gl) & (kDuoRing - 1)] = s;
                     m_idx += naccept;
                     // (wave-uniform lane numbers: v_readlane, not the LDS crossbar of a shuffle)
                     sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), uni(naccept - 1)));
                     dif = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), uni(naccept - 1)));
-                    if (cr) {
-                        const int ts = __builtin_amdgcn_readlane(tk, uni(kl));
+                    if (kl >= 0) {
                         thr = 0; clk = 0;
                         if (ts > thresh) {
                             index = (index + 1 == kPhases) ? 0 : index + 1;
@@ -189,7 +199,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                         }
                         p = p + 2 * kl + 2;
                     } else {
-                        thr += (int)__popcll(um) - (int)__popcll(dm);
+                        thr += nu - nd;
                         const int ilast = p + 2 * (nv - 1);
                         if (ilast + 1 < kDiscOut) { clk = 0; p = ilast + 2; }
                         else { clk = 1; p = kDiscOut; }
