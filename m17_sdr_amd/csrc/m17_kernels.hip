@@ -328,10 +328,9 @@ __device__ __forceinline__ void fq_sum_chunk(const float *row, float &offset, fl
 __global__ __launch_bounds__(64 * FQ_WAVES)
 void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
                   float *__restrict__ disc_raw, float *__restrict__ offs,
-                  int nblk, int total, int update_state, int b0, int bc)
+                  int nblk, int total, int update_state)
 {
-    // total = C * bc rows: row r is block b0 + r % bc of channel r / bc (bc == nblk, b0 == 0: every block of the call,
-    // channel-major; a block range lets the timing stage start on the first blocks while later ones are still here)
+    // total = C * nblk items, channel-major
     __shared__ __attribute__((aligned(16))) uint32_t tile[FQ_WAVES][16 * FQ_STRIDE];  // raw IQ, then u*0.5
     __shared__ __attribute__((aligned(16))) float otile[FQ_WAVES][16 * FQ_STRIDE];    // 64 picked outputs per row
     const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
@@ -339,9 +338,8 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
     const int cb0 = ((int)blockIdx.x * FQ_WAVES + wave) * 16;
     if (cb0 >= total) return;
     const bool valid = (cb0 + cbl) < total;
-    const int rr = valid ? cb0 + cbl : total - 1;
-    const int chan = rr / bc, blk = b0 + rr - chan * bc;
-    const int cb = chan * nblk + blk;                       // the row's index in the channel-major arrays
+    const int cb = valid ? cb0 + cbl : total - 1;
+    const int chan = cb / nblk, blk = cb - chan * nblk;
     uint32_t *my = tile[wave];
     float *myf = reinterpret_cast<float *>(tile[wave]);
     float *myo = otile[wave];
@@ -373,8 +371,6 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
 #endif
     auto row_ptr = [&](int j) {
         int row = cb0 + j * 4 + lr; row = row < total ? row : total - 1;
-        const int rc = row / bc;
-        row = rc * nblk + b0 + row - rc * bc;
 #ifdef M17_STAMPS
         if (dbg & 1) row &= 4095;
 #endif

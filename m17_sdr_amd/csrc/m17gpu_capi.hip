@@ -49,7 +49,6 @@ struct m17gpu_ctx {
                                              // 7 = wave per channel at every size
     int fe_waves_per_cu = 0;                 // experiment: cap of front-end waves per CU (0 = none)
     int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
-    int overlap_blocks = 0;                  // > 1: block chunks, front end of blocks [k+1] beside the timing stage of blocks [k]
     int overlap_chunks = 0;                  // > 1: channel chunks, front end of chunk k+1 beside the timing stage of chunk k (two internal streams)
     hipStream_t aux[2] = {nullptr, nullptr}; // internal streams of the chunked mode, created on first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -159,24 +158,23 @@ inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // Channel range [c0, c0 + cn) of the context (cn < 0: all): every array of the path is channel-major, so a range
 // is the same launch on offset pointers.
 int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc, float *offs,
-                    int update_state, hipStream_t st, int c0 = 0, int cn = -1, int b0 = 0, int bc = -1)
+                    int update_state, hipStream_t st, int c0 = 0, int cn = -1)
 {
     if (cn < 0) cn = ctx->C;
-    if (bc < 0) bc = nblk;
-    const bool quad = ctx->fe_impl != 1 || bc != nblk;       // a block range is the four-lane kernel's
-    const int total = cn * (quad ? bc : nblk);
+    const int total = cn * nblk;
     d_iq += (size_t)c0 * nblk * kBlockSamples * 2;
     disc += (size_t)c0 * nblk * kDiscOut;
     offs += (size_t)c0 * nblk;
     ChanState *state = ctx->d_state + c0;
     // measured on MI355X (scripts/exp_scale.py): the 4-lane kernel wins at 51,200 .. 196,608 channel-blocks,
     // so it is the default at every size; fe_impl 1 keeps the one-lane kernel selectable
+    const bool quad = ctx->fe_impl != 1;
     // fe_waves_per_cu (experiment): unused dynamic LDS caps the front end's waves per CU so that a timing-stage launch on
     // another stream finds register room beside it
     const unsigned pad = ctx->fe_waves_per_cu > 0 ? (unsigned)std::max(0, 160 * 1024 / ctx->fe_waves_per_cu - 8704 - 64) : 0u;
     if (quad)
         hipLaunchKernelGGL(k_frontend_q, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), pad, st,
-                           reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state | (ctx->fe_debug << 1), b0, bc);
+                           reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state | (ctx->fe_debug << 1));
     else
         hipLaunchKernelGGL(k_frontend, dim3(cdiv(total, 64 * FE_WAVES)), dim3(64 * FE_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state);
@@ -374,38 +372,6 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
             }
             MARK(1);
             MARK(2);
-        } else if (ctx->overlap_blocks > 1 && nblk >= 2 * ctx->overlap_blocks) {
-            // Block chunks on two internal streams: the front end of blocks [k+1] beside the timing stage of blocks [k].
-            // This is the small-batch form of the overlap: up to ~2,000 channels the timing stage is a chain of per-block
-            // latencies that leaves most of the chip idle, and the front end (which has no dependence between blocks)
-            // runs in that shadow.  The timing kernels carry their state through ChanState from launch to launch
-            // (b0, bcount: the AFC path already runs them block by block).
-            if (!ctx->aux[0]) {
-                for (hipStream_t &a : ctx->aux) HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-            }
-            const int nch = ctx->overlap_blocks;
-            while ((int)ctx->ev_chunk.size() < nch) {
-                hipEvent_t e;
-                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                ctx->ev_chunk.push_back(e);
-            }
-            HIPCHK(hipEventRecord(ctx->ev_fork, st));
-            HIPCHK(hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
-            HIPCHK(hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
-            for (int k = 0; k < nch; ++k) {
-                const int b0 = (int)((long long)nblk * k / nch), b1 = (int)((long long)nblk * (k + 1) / nch);
-                if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, ctx->aux[0], 0, -1, b0, b1 - b0)) != M17GPU_OK) return rc;
-                HIPCHK(hipEventRecord(ctx->ev_chunk[k], ctx->aux[0]));
-                HIPCHK(hipStreamWaitEvent(ctx->aux[1], ctx->ev_chunk[k], 0));
-                if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
-                                            d_syms, d_nsyms, ctx->aux[1], -1, b0, b1 - b0)) != M17GPU_OK) return rc;
-            }
-            HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux[1]));
-            HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
-            MARK(1);
-            MARK(2);
         } else if (ctx->overlap_chunks > 1 && ctx->C >= 64 * ctx->overlap_chunks) {
             // Channel chunks on two internal streams: the front end of chunk k+1 (HBM-bound) runs beside the timing
             // stage of chunk k (issue/latency-bound).  Both streams fork from the caller's stream and join it again, so
@@ -506,7 +472,6 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "fe_debug")) { ctx->fe_debug = value; }      // instrumented build only: WRONG results
 #endif
     else if (!std::strcmp(name, "fe_waves_per_cu")) { if (value < 0 || value > 32) return bad(); ctx->fe_waves_per_cu = value; }
-    else if (!std::strcmp(name, "overlap_blocks")) { if (value < 0 || value > 16) return bad(); ctx->overlap_blocks = value; }
     else if (!std::strcmp(name, "overlap_chunks")) { if (value < 0 || value > 16) return bad(); ctx->overlap_chunks = value; }
     else return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: unknown option ") + name);
     return M17GPU_OK;
