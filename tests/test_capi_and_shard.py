@@ -154,3 +154,21 @@ def test_parse_lsf_fields_against_survey_kats():
     lsf[6:12] = [0, 0, 0, 0x9F, 0xDD, 0x51]
     L.m17gpu_parse_lsf(lsf.ctypes.data_as(C.c_void_p), C.byref(f))
     assert f.src_call == buf.value == b"AB1CD    " and f.crc_ok == 0
+
+
+def test_traffic_json_comes_from_the_newest_profile_set():
+    """bench.py reads roofline.traffic from profiles/traffic.json (PMC passes cannot run inside the bench process): the
+    file must have been rebuilt from the newest FETCH_SIZE / WRITE_SIZE passes under profiles/, and name them."""
+    import glob
+    import json
+    import re
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    prefixes = sorted({re.match(r"(r\d\d_[a-z])_pmc_FETCH_SIZE_full\.txt", os.path.basename(f)).group(1)
+                       for f in glob.glob(os.path.join(ROOT, "profiles", "r??_?_pmc_FETCH_SIZE_full.txt"))})
+    assert prefixes, "no PMC passes under profiles/"
+    assert tj.get("_profile_prefix") == prefixes[-1], (tj.get("_profile_prefix"), prefixes[-1])
+    assert prefixes[-1] in tj["_comment"]
+    for wl in ("full", "frontend"):
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            assert os.path.exists(os.path.join(ROOT, "profiles", f"{prefixes[-1]}_pmc_{c}_{wl}.txt"))
+    assert tj["full:16384x12"] > 196608 * 7744 and tj["frontend:1024x50"] > 51200 * 8448
