@@ -227,19 +227,21 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
             const v2f a = fir_window_s(xa, (p & 1) != 0);
             WSTAMP(1);
             const float s = a.x, d = a.y;
-            const bool vote_ok = (gl < nv) && (p + 2 * gl + 1 < kDiscOut);
+            // instant g votes at tick p + 2g + 1: the votes this round has are its first nvote lanes (a scalar mask)
+            const int nvote = min(nv, (kDiscOut - p) >> 1);
+            const unsigned long long okm = (nvote >= 64) ? ~0ull : ((1ull << nvote) - 1ull);
             const float dd = (s < 0.0f) ? -d : d;             // sync_update, m17_rx_sync.cpp:38-42
-            const bool up = vote_ok && dd > 0.0f, dn = vote_ok && dd < 0.0f;
-            const unsigned long long um = __builtin_amdgcn_ballot_w64(up);
-            const unsigned long long dm = __builtin_amdgcn_ballot_w64(dn);
+            const unsigned long long um = __builtin_amdgcn_ballot_w64(dd > 0.0f) & okm;
+            const unsigned long long dm = __builtin_amdgcn_ballot_w64(dd < 0.0f) & okm;
             const int nu = (int)__popcll(um), nd = (int)__popcll(dm);
             int naccept = nv, kl = -1, ts_ = 0;
             if (thr + nu > thresh || thr - nd < -thresh) {
                 // a crossing is possible in this round: the counter after every tick, first crossing wins
                 const int pu = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
                 const int pd = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0u));
-                const int tk = thr + pu - pd + (int)up - (int)dn;
-                const unsigned long long cr = __builtin_amdgcn_ballot_w64(vote_ok && (tk > thresh || tk < -thresh));
+                const int own = (int)((um >> gl) & 1ull) - (int)((dm >> gl) & 1ull);
+                const int tk = thr + pu - pd + own;
+                const unsigned long long cr = __builtin_amdgcn_ballot_w64(tk > thresh || tk < -thresh) & okm;
                 if (cr) {
                     kl = (int)__builtin_ctzll(cr);
                     naccept = kl + 1;
