@@ -101,14 +101,6 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
                      m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts,
                      float *d_syms, int32_t *d_nsyms, void *stream);
 
-/* Look-ahead for a streaming host (optional): runs the front end (dsp_short_to_float, dsp_limit, dsp_arctan_disc2)
- * of the NEXT call's input on an internal stream, beside the timing stage / decoder / bookkeeping of the call just
- * enqueued.  Call it right after m17gpu_rx_blocks of the current step, on the same stream, with the device buffer
- * the next m17gpu_rx_blocks will be given: that call (same d_iq, same nblk) then skips its front end.  Results are
- * the same bits either way; one look-ahead may be pending at a time; not for AFC contexts (M17GPU_ERR_ARG).  The
- * caller must leave d_iq_next untouched until the call that consumes it has been enqueued. */
-int m17gpu_rx_blocks_ahead(m17gpu_ctx *ctx, const int16_t *d_iq_next, int nblk, void *stream);
-
 /* ---------------- stage entry points (batched reference functions) -------- */
 /* dsp_short_to_float + dsp_limit + dsp_arctan_disc2 (m17_dsp.cpp:136-141,
  * :412-419, :194-222): d_disc [C][nblk][384] DC-removed discriminator output,

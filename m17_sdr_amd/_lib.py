@@ -55,7 +55,6 @@ SIGNATURES = {
     "m17gpu_demap_frame": (_i, [_vp, _vp, _vp, _i, _vp]),
     "m17gpu_decode_frames": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "m17gpu_golay_decode": (_i, [_vp, _vp, _vp, _i, _vp]),
-    "m17gpu_rx_blocks_ahead": (_i, [_vp, _vp, _i, _vp]),
     "m17gpu_set_option": (_i, [_vp, C.c_char_p, _i]),
     "m17gpu_set_profiling": (_i, [_vp, _i]),
     "m17gpu_get_kernel_ms": (_i, [_vp, _vp, _vp]),

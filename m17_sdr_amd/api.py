@@ -100,16 +100,6 @@ class Receiver:
                                       _ptr(out["nsyms"]), self._stream()), "m17gpu_rx_blocks")
         return out
 
-    def rx_blocks_ahead(self, iq_next):
-        """Look-ahead: the front end of the NEXT step's input beside the later stages of the step just enqueued.
-        Call right after rx_blocks(); the next rx_blocks(iq_next, ...) then skips its front end (same results)."""
-        import torch
-        if not isinstance(iq_next, torch.Tensor) or iq_next.dim() != 4:
-            raise ValueError("iq_next must be a [C, nblk, 1920, 2] int16 tensor")
-        nblk = int(iq_next.shape[1])
-        self._chk(iq_next, torch.int16, (self.C, nblk, 1920, 2), "iq_next")
-        _check(lib().m17gpu_rx_blocks_ahead(self._ctx, _ptr(iq_next), nblk, self._stream()), "m17gpu_rx_blocks_ahead")
-
     def _chk_out(self, out, nblk):
         """Outputs must have been allocated for this receiver and this block count: the symbol rows
         are nblk*193+8 floats apart and nsyms is [C, nblk]."""

@@ -36,12 +36,6 @@ struct m17gpu_ctx {
     int device = 0, C = 0, max_blocks = 0, rec_cap_max = 0;
     ChanState *d_state = nullptr;
     float *d_disc = nullptr, *d_offs = nullptr, *d_fsym = nullptr;
-    // look-ahead (m17gpu_rx_blocks_ahead): the front end of the NEXT call into a second discriminator buffer
-    float *d_disc2 = nullptr, *d_offs2 = nullptr;
-    const int16_t *ahead_iq = nullptr;       // input the look-ahead front end was run on (nullptr: none pending)
-    int ahead_nblk = 0;
-    hipStream_t ahead_stream = nullptr;
-    hipEvent_t ev_ahead = nullptr, ev_fe = nullptr, ev_call = nullptr;   // look-ahead done | last front end enqueued | last call started
     int32_t *d_work = nullptr, *d_nwork = nullptr, *d_counts = nullptr;
     uint16_t *d_genc = nullptr, *d_gerr = nullptr, *d_crc_basis = nullptr;
     uint32_t *d_dec_hist = nullptr;          // [C][32] history of the wide-band decimator
@@ -310,9 +304,6 @@ void m17gpu_destroy(m17gpu_ctx *ctx)
 {
     if (!ctx) return;
     DeviceScope dev_scope_(ctx->device);
-    for (hipEvent_t e : {ctx->ev_ahead, ctx->ev_fe, ctx->ev_call}) if (e) (void)hipEventDestroy(e);
-    if (ctx->ahead_stream) (void)hipStreamDestroy(ctx->ahead_stream);
-    (void)hipFree(ctx->d_disc2); (void)hipFree(ctx->d_offs2);
     void *bufs[] = {ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->d_fsym, ctx->d_work,
                     ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis, ctx->d_dec_hist};
     for (void *p : bufs) (void)hipFree(p);
@@ -413,18 +404,7 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
             MARK(1);
             MARK(2);
         } else {
-            if (ctx->ev_call) HIPCHK(hipEventRecord(ctx->ev_call, st));      // everything of the previous call precedes this point
-            if (ctx->ahead_iq && ctx->ahead_iq == d_iq && ctx->ahead_nblk == nblk) {
-                // this call's front end already ran (m17gpu_rx_blocks_ahead) beside the previous call's later stages
-                HIPCHK(hipStreamWaitEvent(st, ctx->ev_ahead, 0));
-                std::swap(ctx->d_disc, ctx->d_disc2);
-                std::swap(ctx->d_offs, ctx->d_offs2);
-            } else {
-                if (ctx->ahead_iq) HIPCHK(hipStreamWaitEvent(st, ctx->ev_ahead, 0));   // a look-ahead for other input: keep the state order
-                if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, st)) != M17GPU_OK) return rc;
-            }
-            ctx->ahead_iq = nullptr;
-            if (ctx->ev_fe) HIPCHK(hipEventRecord(ctx->ev_fe, st));
+            if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, st)) != M17GPU_OK) return rc;
             MARK(1);
             if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
                                         d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
@@ -437,41 +417,6 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
 #undef MARK
     }
     if (ev) HIPCHK(hipEventRecord(ev[6], st));
-    return M17GPU_OK;
-}
-
-// Look-ahead for a streaming host: the front end of the NEXT call's input, on an internal stream, beside the timing
-// stage / decoder / bookkeeping of the call just enqueued (they are bound by vector and scalar issue, the front end
-// by the memory pipeline).  Call it right AFTER m17gpu_rx_blocks of the current step, on the same stream; the next
-// m17gpu_rx_blocks with exactly this d_iq and nblk then skips its front end.  The discriminator memory z[0], z[1]
-// (m17_dsp.cpp:196) chains from call to call, so the look-ahead is ordered behind the current call's front end; its
-// output goes to a second workspace buffer that the previous call's timing stage no longer reads.
-int m17gpu_rx_blocks_ahead(m17gpu_ctx *ctx, const int16_t *d_iq_next, int nblk, void *stream)
-{
-    if (!ctx || !d_iq_next || nblk <= 0 || nblk > ctx->max_blocks)
-        return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks_ahead: bad argument (nblk must be 1..max_blocks)");
-    if (ctx->afc) return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks_ahead: an AFC context runs block by block (no look-ahead)");
-    if (ctx->ahead_iq) return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks_ahead: a look-ahead is already pending");
-    ON_CTX_DEVICE(ctx);
-    hipStream_t st = S(stream);
-    if (!ctx->ahead_stream) {
-        const size_t cb = (size_t)ctx->C * ctx->max_blocks;
-        HIPCHK(hipMalloc(&ctx->d_disc2, sizeof(float) * cb * kDiscOut));
-        HIPCHK(hipMalloc(&ctx->d_offs2, sizeof(float) * cb));
-        HIPCHK(hipStreamCreateWithFlags(&ctx->ahead_stream, hipStreamNonBlocking));
-        for (hipEvent_t *e : {&ctx->ev_ahead, &ctx->ev_fe, &ctx->ev_call}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        // no call has recorded the two ordering events yet: everything enqueued so far on the caller's stream stands in
-        HIPCHK(hipEventRecord(ctx->ev_call, st));
-        HIPCHK(hipEventRecord(ctx->ev_fe, st));
-    }
-    // behind the current call's front end (state order) and behind the start of the current call (the buffer written
-    // here was last read by the call before it)
-    HIPCHK(hipStreamWaitEvent(ctx->ahead_stream, ctx->ev_fe, 0));
-    HIPCHK(hipStreamWaitEvent(ctx->ahead_stream, ctx->ev_call, 0));
-    int rc = launch_frontend(ctx, d_iq_next, nblk, ctx->d_disc2, ctx->d_offs2, 1, ctx->ahead_stream);
-    if (rc != M17GPU_OK) return rc;
-    HIPCHK(hipEventRecord(ctx->ev_ahead, ctx->ahead_stream));
-    ctx->ahead_iq = d_iq_next; ctx->ahead_nblk = nblk;
     return M17GPU_OK;
 }
 
