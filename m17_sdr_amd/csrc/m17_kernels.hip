@@ -325,6 +325,14 @@ __device__ __forceinline__ void fq_sum_chunk(const float *row, float &offset, fl
     }
 }
 
+#ifdef M17_STAMPS
+__device__ unsigned long long g_fe_stamps[8];
+__device__ unsigned long long g_fe_span[16384][2];        // start / end s_memtime of the first 16,384 workgroups
+#define FSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0); facc_[i] += now_ - flast_; flast_ = now_; } while (0)
+#else
+#define FSTAMP(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(64 * FQ_WAVES)
 void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
                   float *__restrict__ disc_raw, float *__restrict__ offs,
@@ -389,9 +397,14 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
 
     float offset = 0.0f;
     float *dst = disc_raw + (size_t)cb * kDiscOut;
+#ifdef M17_STAMPS
+    unsigned long long facc_[6] = {0, 0, 0, 0, 0, 0}, flast_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long fstart_ = flast_;
+#endif
 
     auto chunk_body = [&](int chunk, auto c5tag) {
         constexpr int C5 = decltype(c5tag)::value;
+        FSTAMP(5);
         // raw tile in, next chunk's loads out
         *reinterpret_cast<uint4 *>(&my[l0]) = s0;
         *reinterpret_cast<uint4 *>(&my[l1]) = s1;
@@ -409,6 +422,7 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
             w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
         }
         wave_lds_sync();                                       // every lane holds its samples: the tile is free
+        FSTAMP(0);
         float pre[16], pim[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -439,8 +453,10 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
             *reinterpret_cast<float4 *>(&myf[cbl * FQ_STRIDE + sub * 16 + q * 4]) = make_float4(uh[0], uh[1], uh[2], uh[3]);
         }
         wave_lds_sync();
+        FSTAMP(1);
         if (sub == 0) fq_sum_chunk<C5>(&myf[cbl * FQ_STRIDE], offset, &myo[cbl * FQ_STRIDE]);
         wave_lds_sync();
+        FSTAMP(2);
     };
 
     for (int it = 0; it < FQ_NCHUNK / 5; ++it) {
@@ -460,6 +476,10 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
         }
         wave_lds_sync();
     }
+#ifdef M17_STAMPS
+    if (blockIdx.x == 777 && lane == 0) for (int i = 0; i < 6; ++i) g_fe_stamps[i] = facc_[i];
+    if (blockIdx.x < 16384 && lane == 0) { g_fe_span[blockIdx.x][0] = fstart_; g_fe_span[blockIdx.x][1] = __builtin_amdgcn_s_memtime(); }
+#endif
     if (sub == 0 && valid) {
         offs[cb] = offset / (float)kBlockSamples;
         if (update_state && blk == 0) {

@@ -427,6 +427,18 @@ int m17gpu_debug_stamps(unsigned long long *out)
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16));
     return 0;
 }
+int m17gpu_debug_fe_stamps(unsigned long long *out /* [8] */)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fe_stamps), sizeof(unsigned long long) * 8));
+    return 0;
+}
+int m17gpu_debug_fe_span(unsigned long long *out /* [16384][2] */)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fe_span), sizeof(unsigned long long) * 16384 * 2));
+    return 0;
+}
 int m17gpu_debug_chan_stamps(unsigned long long *out /* [4096][8] */)
 {
     HIPCHK(hipDeviceSynchronize());
