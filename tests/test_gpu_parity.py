@@ -167,6 +167,7 @@ def test_every_kernel_variant_is_bit_exact(options):
     _rx_compare(C=40, nblk=22, mode=1, ebn0=200.0, nsf=12, options=options)
     _rx_compare(C=40, nblk=9, mode=1, ebn0=9.0, nsf=5, calls=3, options=options)
     _rx_compare(C=9, nblk=1, mode=0, ebn0=15.0, calls=12, options=options)
+    _rx_compare(C=24, nblk=14, mode=1, ebn0=200.0, packet_mode=1, options=options)       # packet reassembly too
     if "overlap_chunks" in options:          # the chunked path needs >= 64 channels per chunk
         _rx_compare(C=300, nblk=7, mode=1, ebn0=9.0, nsf=5, calls=2, options=options)
 
@@ -466,6 +467,8 @@ def test_record_capacity_overflow_and_max_blocks():
     sig = m.generate_batch(6, 40, n_stream_frames=40, ebn0_db=200.0)
     counts, _ = _compare_raw(np.ascontiguousarray(sig["iq"][:, :20]), mode=0, rec_cap=5)
     assert counts.max() > 5
+    counts, _ = _compare_raw(np.ascontiguousarray(sig["iq"][:, :20]), mode=0, rec_cap=5, options={"sync_impl": 7})
+    assert counts.max() > 5
     # two calls with overflow in the first: framer / timing state must carry on exactly
     rx = m.Receiver(6, 20)
     och = oracle.Channels(6)
@@ -675,7 +678,8 @@ def test_stage_decode_frames_mixed_types_and_golay():
     rx.close()
 
 
-def test_afc_loop_tolerance_parity_on_frequency_offsets():
+@pytest.mark.parametrize("sync_impl", [0, 7])
+def test_afc_loop_tolerance_parity_on_frequency_offsets(sync_impl):
     """the AFC branch (dsp_nco_mixer m17_dsp.cpp:390-408,468; radio_afc /
     radio_get_afc_delta radio.cpp:196-208), off by default in the reference and here.  Channels with carrier
     offsets of up to +-500 Hz: the GPU context with "afc" on must decode the same payloads as the oracle with AFC
@@ -693,6 +697,7 @@ def test_afc_loop_tolerance_parity_on_frequency_offsets():
     shifted = np.ascontiguousarray(shifted.reshape(C, nblk * calls, 1920, 2))
     rx = m.Receiver(C, nblk)
     rx.set_option("afc", 1)
+    rx.set_option("sync_impl", sync_impl)
     och = oracle.Channels(C)
     och.set_afc(True)
     got_pay, want_pay = [[] for _ in range(C)], [[] for _ in range(C)]
