@@ -66,131 +66,6 @@ __device__ __forceinline__ void duo_post_lds(int *flag, int value, int lane)
     if (lane == 0) lds_poke(flag, value);
 }
 
-// The framer wave of a channel whose timing side publishes blocks through the mailbox words of CH (H ring of RING
-// floats, nsym[4], lock_after[4], tim_blk, frm_blk): one block behind, symbol stream out, frame-sync checks, records,
-// frame symbols (m17_rx_frame.cpp:126-177).  Shared by k_sync_frame_duo and k_sync_frame_par.
-template <int RING, class CH>
-__device__ __forceinline__ void framer_wave(CH &my, ChanState &cs, int chan, int gl, int nblk, int mode,
-                                            m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
-                                            float *__restrict__ syms, int32_t *__restrict__ nsyms,
-                                            float *__restrict__ fsym, int b0, int bcount)
-{
-    constexpr int LPC = 64;
-    const int bend = b0 + bcount;
-    int *tim_blk = &my.tim_blk, *frm_blk = &my.frm_blk;
-#ifdef M17_STAMPS
-    unsigned long long acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, last_ = __builtin_amdgcn_s_memtime();
-#endif
-    m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
-    if (!recs) rec_cap = 0;
-    int flock = cs.flock, fclk = cs.fclk, ferr = cs.ferr;
-    uint32_t block_count = cs.block_count;
-    int nrec = (b0 == 0) ? 0 : counts[chan];
-    int sym_total = (b0 == 0) ? 0 : cs.sym_total;
-    int hp = 256;
-    RegroupLane<LPC> rg;
-    rg.load(gl);
-    const unsigned sgn = sync_sign_mask(gl);
-    // m_f_sym[0 .. fclk) is the frame in progress: ring [hp - fclk, hp); m_sync is the last 8 symbols.
-    // Only positions below hp are written here: hp upward belongs to the timing wave from the start.
-    if (flock) { for (int q = gl; q < fclk; q += LPC) my.H[(hp - fclk + q) & (RING - 1)] = cs.fsym[q]; }
-    else if (gl < 8) my.H[(hp - 8 + gl) & (RING - 1)] = cs.sync[gl];
-    float *sym_out = syms ? syms + (size_t)chan * M17_SYM_STRIDE(nblk) + sym_total : nullptr;
-    wave_fence();
-    for (int b = b0; b < bend; ++b) {
-        STAMP(2);
-        duo_wait<8>(tim_blk, b - b0 + 1);
-        STAMP(3);
-        const int n = lds_peek(&my.nsym[b & 3]);
-        if (sym_out) {
-#pragma unroll
-            for (int r = 0; r < (193 + LPC - 1) / LPC; ++r) {
-                const int q = gl + LPC * r;
-                if (q < n) sym_out[q] = my.H[(hp + q) & (RING - 1)];
-            }
-            sym_out += n;
-        }
-        if (nsyms && gl == 0) nsyms[(size_t)chan * nblk + b] = n;
-        sym_total += n;
-        // ---- framer (m17_rx_frame.cpp:126-177) over ring symbols hp .. hp+n-1
-        int pos = 0;
-        while (pos < n) {
-            if (flock) {
-                const int cnt = min(kFrameSyms - fclk, n - pos);
-                fclk += cnt; pos += cnt;
-                if (fclk == kFrameSyms) {
-                    fclk = 0;
-                    const int fs = hp + pos - kFrameSyms;               // the frame sits in the ring, in place
-                    const SyncResult r = sync_check_lanes8(my.H[(fs + (gl & 7)) & (RING - 1)], sgn);
-                    uint32_t flags = 0;
-                    bool parse = false, unlock = false;
-                    if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
-                    else if (sync_accept(r, true)) { flags |= M17_F_SYNC_OK; parse = true; ferr = 0; }
-                    else {
-                        ferr++;
-                        if (ferr > 5) { flags |= M17_F_LOST; unlock = true; }
-                        else parse = true;
-                    }
-                    if (parse && mode == 1) flags |= M17_F_PARSED;
-                    const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
-                    emit_record_wave(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
-                    if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
-                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kSlotFloats;
-                        store_frame_slot<LPC>(fd, r.type, gl, rg, [&](int q) { return my.H[(fs + q) & (RING - 1)]; });
-                    }
-                    nrec++;
-                    if (unlock) {
-                        flock = 0;
-                        // reset_sync(): the next hunt windows must see zeros behind them
-                        wave_fence();
-                        if (gl < 8) my.H[(hp + pos - 8 + gl) & (RING - 1)] = 0.0f;
-                        wave_fence();
-                    }
-                }
-            } else {
-                // hunt: candidate symbol j = pos+gl, window = ring [hp+j-7, hp+j]
-                const int jc = pos + gl;
-                const bool cand = jc < n;
-                const int jj = cand ? jc : pos;
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = my.H[(hp + jj - 7 + i) & (RING - 1)];
-                SyncResult r; r.type = 0; r.votes = 8; r.variance = 1.0f;
-                if (cand && hunt_compatible(v)) r = sync_check(v);           // most windows are rejected by sign
-                const unsigned long long hm = __builtin_amdgcn_ballot_w64(cand && sync_accept(r, false));
-                if (hm) {
-                    const int l = (int)__ffsll((long long)hm) - 1;
-                    const int js = pos + l;
-                    // copy_sync(); m_fclk = 8; lock; m17_aos(): the window already is the head of the frame
-                    fclk = 8; ferr = 0; flock = 1;
-                    const int ty = __shfl(r.type, l, 64), vo = __shfl(r.votes, l, 64);
-                    const float va = __shfl(r.variance, l, 64);
-                    emit_record_wave(crecs, rec_cap, nrec, gl, (uint32_t)ty | ((uint32_t)vo << 8), M17_F_AOS, va,
-                                    block_count, (uint32_t)js);
-                    nrec++;
-                    pos = js + 1;
-                } else {
-                    pos = min(n, pos + LPC);
-                }
-            }
-        }
-        hp += n;
-        block_count++;
-        if (gl == 0) my.lock_after[b & 3] = flock;
-        duo_post(frm_blk, b - b0 + 1, gl);
-    }
-#ifdef M17_STAMPS
-    if (chan == 0 && gl == 0) { g_stamps[2] = acc_[2]; g_stamps[3] = acc_[3]; }
-#endif
-    // ---- store state in the reference's layout
-    if (gl == 0) {
-        cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count; cs.sym_total = sym_total;
-        if (counts) counts[chan] = nrec;
-    }
-    if (flock) { for (int q = gl; q < kFrameSyms; q += LPC) cs.fsym[q] = my.H[(hp - fclk + q) & (RING - 1)]; }
-    else if (gl < 8) cs.sync[gl] = my.H[(hp - 8 + gl) & (RING - 1)];
-}
-
 __global__ __launch_bounds__(512)
 void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                       const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
@@ -368,7 +243,115 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
         return;
     }
 
-    framer_wave<kDuoRing>(my, cs, chan, gl, nblk, mode, recs, rec_cap, counts, syms, nsyms, fsym, b0, bcount);
+    // =========================== framer wave ===========================
+    m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
+    if (!recs) rec_cap = 0;
+    int flock = cs.flock, fclk = cs.fclk, ferr = cs.ferr;
+    uint32_t block_count = cs.block_count;
+    int nrec = (b0 == 0) ? 0 : counts[chan];
+    int sym_total = (b0 == 0) ? 0 : cs.sym_total;
+    int hp = 256;
+    RegroupLane<LPC> rg;
+    rg.load(gl);
+    const unsigned sgn = sync_sign_mask(gl);
+    // m_f_sym[0 .. fclk) is the frame in progress: ring [hp - fclk, hp); m_sync is the last 8 symbols.
+    // Only positions below hp are written here: hp upward belongs to the timing wave from the start.
+    if (flock) { for (int q = gl; q < fclk; q += LPC) my.H[(hp - fclk + q) & (kDuoRing - 1)] = cs.fsym[q]; }
+    else if (gl < 8) my.H[(hp - 8 + gl) & (kDuoRing - 1)] = cs.sync[gl];
+    float *sym_out = syms ? syms + (size_t)chan * M17_SYM_STRIDE(nblk) + sym_total : nullptr;
+    wave_fence();
+    for (int b = b0; b < bend; ++b) {
+        STAMP(2);
+        duo_wait<8>(tim_blk, b - b0 + 1);
+        STAMP(3);
+        const int n = lds_peek(&my.nsym[b & 3]);
+        if (sym_out) {
+#pragma unroll
+            for (int r = 0; r < (193 + LPC - 1) / LPC; ++r) {
+                const int q = gl + LPC * r;
+                if (q < n) sym_out[q] = my.H[(hp + q) & (kDuoRing - 1)];
+            }
+            sym_out += n;
+        }
+        if (nsyms && gl == 0) nsyms[(size_t)chan * nblk + b] = n;
+        sym_total += n;
+        // ---- framer (m17_rx_frame.cpp:126-177) over ring symbols hp .. hp+n-1
+        int pos = 0;
+        while (pos < n) {
+            if (flock) {
+                const int cnt = min(kFrameSyms - fclk, n - pos);
+                fclk += cnt; pos += cnt;
+                if (fclk == kFrameSyms) {
+                    fclk = 0;
+                    const int fs = hp + pos - kFrameSyms;               // the frame sits in the ring, in place
+                    const SyncResult r = sync_check_lanes8(my.H[(fs + (gl & 7)) & (kDuoRing - 1)], sgn);
+                    uint32_t flags = 0;
+                    bool parse = false, unlock = false;
+                    if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
+                    else if (sync_accept(r, true)) { flags |= M17_F_SYNC_OK; parse = true; ferr = 0; }
+                    else {
+                        ferr++;
+                        if (ferr > 5) { flags |= M17_F_LOST; unlock = true; }
+                        else parse = true;
+                    }
+                    if (parse && mode == 1) flags |= M17_F_PARSED;
+                    const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
+                    emit_record_wave(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
+                    if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
+                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kSlotFloats;
+                        store_frame_slot<LPC>(fd, r.type, gl, rg, [&](int q) { return my.H[(fs + q) & (kDuoRing - 1)]; });
+                    }
+                    nrec++;
+                    if (unlock) {
+                        flock = 0;
+                        // reset_sync(): the next hunt windows must see zeros behind them
+                        wave_fence();
+                        if (gl < 8) my.H[(hp + pos - 8 + gl) & (kDuoRing - 1)] = 0.0f;
+                        wave_fence();
+                    }
+                }
+            } else {
+                // hunt: candidate symbol j = pos+gl, window = ring [hp+j-7, hp+j]
+                const int jc = pos + gl;
+                const bool cand = jc < n;
+                const int jj = cand ? jc : pos;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = my.H[(hp + jj - 7 + i) & (kDuoRing - 1)];
+                SyncResult r; r.type = 0; r.votes = 8; r.variance = 1.0f;
+                if (cand && hunt_compatible(v)) r = sync_check(v);           // most windows are rejected by sign
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(cand && sync_accept(r, false));
+                if (hm) {
+                    const int l = (int)__ffsll((long long)hm) - 1;
+                    const int js = pos + l;
+                    // copy_sync(); m_fclk = 8; lock; m17_aos(): the window already is the head of the frame
+                    fclk = 8; ferr = 0; flock = 1;
+                    const int ty = __shfl(r.type, l, 64), vo = __shfl(r.votes, l, 64);
+                    const float va = __shfl(r.variance, l, 64);
+                    emit_record_wave(crecs, rec_cap, nrec, gl, (uint32_t)ty | ((uint32_t)vo << 8), M17_F_AOS, va,
+                                    block_count, (uint32_t)js);
+                    nrec++;
+                    pos = js + 1;
+                } else {
+                    pos = min(n, pos + LPC);
+                }
+            }
+        }
+        hp += n;
+        block_count++;
+        if (gl == 0) my.lock_after[b & 3] = flock;
+        duo_post(frm_blk, b - b0 + 1, gl);
+    }
+#ifdef M17_STAMPS
+    if (chan == 0 && gl == 0) { g_stamps[2] = acc_[2]; g_stamps[3] = acc_[3]; }
+#endif
+    // ---- store state in the reference's layout
+    if (gl == 0) {
+        cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count; cs.sym_total = sym_total;
+        if (counts) counts[chan] = nrec;
+    }
+    if (flock) { for (int q = gl; q < kFrameSyms; q += LPC) cs.fsym[q] = my.H[(hp - fclk + q) & (kDuoRing - 1)]; }
+    else if (gl < 8) cs.sync[gl] = my.H[(hp - 8 + gl) & (kDuoRing - 1)];
 }
 
 } // namespace m17dev

@@ -75,16 +75,6 @@ __device__ __forceinline__ v2f fir_window_s(unsigned lds_pair, bool odd)
     else      asm volatile(M17_FIR_SGPR_ODD : M17_FIR_OPERANDS : [a] "v"(lds_pair) : "memory");
     return acc;
 }
-// The same round with the branch's tap row loaded inside the statement (k_sync_frame_par's filter waves): s[40:101]
-// is live only between the statement's first and last instruction, so the kernel needs no SGPR limit for the
-// registers to survive -- its control wave gets the whole scalar file.
-__device__ __forceinline__ v2f fir_window_ld_s(const float *row, unsigned lds_pair, bool odd)
-{
-    v2f acc, P, Q, x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
-    if (!odd) asm volatile(M17_FIR_SGPR_LD_EVEN : M17_FIR_OPERANDS : [a] "v"(lds_pair), [row] "s"(row) : "memory", M17_TAP_CLOBBERS);
-    else      asm volatile(M17_FIR_SGPR_LD_ODD : M17_FIR_OPERANDS : [a] "v"(lds_pair), [row] "s"(row) : "memory", M17_TAP_CLOBBERS);
-    return acc;
-}
 typedef const __attribute__((address_space(3))) float *lds_cfp;
 
 __device__ __forceinline__ float readlane_f(float v, int l)

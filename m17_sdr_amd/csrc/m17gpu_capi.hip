@@ -5,7 +5,6 @@
 #include "m17_sync_common.hip"
 #include "m17_sync_duo.hip"
 #include "m17_sync_wave.hip"
-#include "m17_sync_par.hip"
 #include "m17_decode_quad.hip"
 #include "m17_book.hip"
 #include "m17_pluto.hip"
@@ -201,12 +200,7 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
     // 1,024 channels -- a second workgroup per CU does not fit its registers; beyond that, and for the lock-forced
     // stage entry, which has no framer, one wave per channel with scalar control (m17_sync_wave.hip)
     const bool duo = (ctx->sync_impl == 0 || ctx->sync_impl == 6) && ctx->C <= 1024 && ext_lock < 0;
-    const bool par = ctx->sync_impl == 8 && ext_lock < 0;
-    if (par)
-        hipLaunchKernelGGL(k_sync_frame_par, dim3(cn), dim3(512), 0, st,
-                           disc, offs, state, cn, nblk, mode, recs, recs ? rec_cap : 0,
-                           counts, syms, nsyms, fsym, b0, bcount);
-    else if (duo)
+    if (duo)
         hipLaunchKernelGGL(k_sync_frame_duo, dim3(cdiv(cn, 4)), dim3(512), 0, st,
                            disc, offs, state, cn, nblk, mode, recs, recs ? rec_cap : 0,
                            counts, syms, nsyms, fsym, b0, bcount);
@@ -483,7 +477,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
     auto bad = [&]() { return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: value out of range for ") + name); };
-    if (!std::strcmp(name, "sync_impl")) { if (value != 0 && value != 6 && value != 7 && value != 8) return bad(); ctx->sync_impl = value; }
+    if (!std::strcmp(name, "sync_impl")) { if (value != 0 && value != 6 && value != 7) return bad(); ctx->sync_impl = value; }
     else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 2) return bad(); ctx->fe_impl = value; }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
 #ifdef M17_STAMPS
