@@ -131,13 +131,13 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
     WvChan &my = chs[wave];
     const unsigned hb = (unsigned)uni((int)(unsigned)(uintptr_t)(lds_cfp)my.H);       // LDS byte address of the ring
     ChanState &cs = st[chan];
-    const unsigned sgn = sync_sign_mask(gl);
     m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
     if (!recs) rec_cap = 0;
 
     // wave-uniform control state: scalar registers
     int clk = uni(cs.clk), thr = uni(cs.thr), index = uni(cs.index);
-    float sum = unif(cs.sum), dif = unif(cs.dif);
+    float cs_ = cs.sum, cd_ = cs.dif;                        // carried (sum, dif): lane `clane` of these
+    int clane = 0;
     int flock = uni(cs.flock), fclk = uni(cs.fclk), ferr = uni(cs.ferr);
     uint32_t block_count = (uint32_t)uni((int)cs.block_count);
     int nrec = (b0 == 0) ? 0 : uni(counts[chan]);
@@ -165,6 +165,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
     wave_fence();
 
     int tap_index = -1;                                      // the branch whose tap pairs are in s[40:101]
+    const unsigned xb = (unsigned)uni((int)(unsigned)(uintptr_t)(lds_cfp)my.x);       // LDS byte address of x[]
     const int bend = b0 + bcount;
 #ifdef M17_STAMPS
     // phase accumulators in LDS (the scalar registers are spoken for): lane 0 adds the ticks since the last stamp
@@ -180,55 +181,48 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
 #endif
     for (int b = b0; b < bend; ++b) {
         WSTAMP(5);
-        // next block's input: loads issued now, committed at the end of the block
-        constexpr int PF = kDiscOut / LPC;
-        float pf[PF];
-        float noff = 0.0f;
-        if (b + 1 < bend) {
-            const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
-            noff = osrc ? osrc[b + 1] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < PF; ++r) pf[r] = __builtin_nontemporal_load(&nx[gl + LPC * r]);   // read once
-        }
-
         // ---- timing recovery in rounds of 64 instants; x[i .. i+30] is the delay line at input i
         const int lockv = (ext_lock >= 0) ? ext_lock : flock;        // m17_rx_lock(): the framer's state after the previous block
         const int thresh = lockv ? 80 : 10;
         int p = 0, m_idx = 0;
-        while (p < kDiscOut) {
-            if (clk == 1) {
-                // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72)
-                clk = 0;
-                const float d0 = (sum < 0.0f) ? -dif : dif;
-                if (d0 > 0.0f) thr++;
-                if (d0 < 0.0f) thr--;
-                if (thr > thresh) {
-                    index = (index + 1 == kPhases) ? 0 : index + 1; thr = 0;
-                    if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.H[(hp + m_idx) & RM] = 0.0f; m_idx++; }
-                }
-                if (thr < -thresh) {
-                    thr = 0; index = (index == 0) ? kPhases - 1 : index - 1;
-                    if (index == kPhases - 1) { clk = 1; m_idx--; }
-                }
-                p++;
-                WSTAMP(0);
-                continue;
+        // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72): the first input of a block whose
+        // predecessor ended on a filter instant, and the input behind a wrap of the branch
+        auto tick = [&]() {
+            clk = 0;
+            const float sum = readlane_f(cs_, clane), dif = readlane_f(cd_, clane);
+            const float d0 = (sum < 0.0f) ? -dif : dif;
+            if (d0 > 0.0f) thr++;
+            if (d0 < 0.0f) thr--;
+            if (thr > thresh) {
+                index = (index + 1 == kPhases) ? 0 : index + 1; thr = 0;
+                if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.H[(hp + m_idx) & RM] = 0.0f; m_idx++; }
             }
+            if (thr < -thresh) {
+                thr = 0; index = (index == 0) ? kPhases - 1 : index - 1;
+                if (index == kPhases - 1) { clk = 1; m_idx--; }
+            }
+            p++;
+        };
+        while (clk == 1 && p < kDiscOut) tick();
+        while (p < kDiscOut) {
             WCNT(8);
             if (tap_index != index) {
+                WSTAMP(0);
                 load_taps_s(&c_tab.tap_pairs[index][0]);
                 tap_index = index;
                 WCNT(9);
+                WSTAMP(6);
             }
             WSTAMP(0);
-            const int rem = (kDiscOut - p + 1) >> 1;          // filter instants left in the block
-            const int nv = rem < LPC ? rem : LPC;
-            const unsigned xa = (unsigned)(uintptr_t)(lds_cfp)(my.x + (p & ~1) + 2 * (gl < nv ? gl : 0));
-            const v2f a = fir_window_s(xa, (p & 1) != 0);
+            // Lane g takes the instant at input p + 2g.  Near the end of the block the upper lanes run past it: their
+            // windows read whatever follows x[] in LDS (reads beyond the allocation return zero), and nothing of theirs
+            // is used -- no vote (okm), no symbol (naccept <= nv), no carried value.
+            const v2f a = fir_window_s(((unsigned)gl << 3) + (xb + ((unsigned)(p & ~1) << 2)), (p & 1) != 0);
             WSTAMP(1);
             const float s = a.x, d = a.y;
-            // instant g votes at tick p + 2g + 1: the votes this round has are its first nvote lanes (a scalar mask)
-            const int nvote = min(nv, (kDiscOut - p) >> 1);
+            const int rem = kDiscOut - p;                     // >= 1
+            const int nv = min(LPC, (rem + 1) >> 1);          // filter instants of this round
+            const int nvote = min(LPC, rem >> 1);             // ... whose vote tick p + 2g + 1 is inside the block
             const unsigned long long okm = (nvote >= 64) ? ~0ull : ((1ull << nvote) - 1ull);
             const float dd = (s < 0.0f) ? -d : d;             // sync_update, m17_rx_sync.cpp:38-42
             const unsigned long long um = __builtin_amdgcn_ballot_w64(dd > 0.0f) & okm;
@@ -250,8 +244,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
             }
             if (gl < naccept && (m_idx + gl) >= 0) ring_st(hp + m_idx + gl, hb, s);
             m_idx += naccept;
-            sum = readlane_f(s, naccept - 1);
-            dif = readlane_f(d, naccept - 1);
+            cs_ = s; cd_ = d; clane = naccept - 1;            // the carried sum/dif stay in their lane until a tick needs them
             if (kl >= 0) {
                 thr = 0; clk = 0;
                 if (ts_ > thresh) {
@@ -262,16 +255,28 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                     if (index == kPhases - 1) { clk = 1; m_idx--; }
                 }
                 p = p + 2 * kl + 2;
+                while (clk == 1 && p < kDiscOut) tick();       // a wrap: the next input is a vote tick again
             } else {
                 thr += nu - nd;
-                const int ilast = p + 2 * (nv - 1);
-                if (ilast + 1 < kDiscOut) { clk = 0; p = ilast + 2; }
-                else { clk = 1; p = kDiscOut; }                     // the last vote tick falls into the next block
+                p += 2 * nv;                                   // behind the last instant's vote tick ...
+                clk = p > kDiscOut ? 1 : 0;                    // ... which falls into the next block when that instant is input 383
+                p = min(p, kDiscOut);
             }
             WSTAMP(2);
         }
         const int n = m_idx > 0 ? m_idx : 0;
         wave_fence();
+        // next block's input: requested here, behind the filter rounds (whose 40-odd window registers leave no room
+        // for six more), and moved into x[] at the end of the block, behind the framer
+        constexpr int PF = kDiscOut / LPC;
+        float pf[PF];
+        float noff = 0.0f;
+        if (b + 1 < bend) {
+            const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
+            noff = osrc ? osrc[b + 1] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < PF; ++r) pf[r] = __builtin_nontemporal_load(&nx[gl + LPC * r]);   // read once
+        }
 
         // symbols out (optional)
         if (sym_out) {
@@ -296,7 +301,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                 if (fclk == kFrameSyms) {
                     fclk = 0;
                     const int fs = hp + pos - kFrameSyms;               // the frame sits in the ring, in place
-                    const SyncResult r = sync_check_lanes8(ring_ld(fs + (gl & 7), hb), sgn);
+                    const SyncResult r = sync_check_lanes8(ring_ld(fs + (gl & 7), hb), sync_sign_mask(gl));
                     uint32_t flags = 0;
                     bool parse = false, unlock = false;
                     if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
@@ -369,11 +374,12 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
 
 #ifdef M17_STAMPS
     WSTAMP(5);
-    if (chan < 4096 && gl < 8) g_chan_stamps[chan][gl] = wstamps[wave][gl < 6 ? gl : gl + 2];
+    if (chan < 4096 && gl < 8) g_chan_stamps[chan][gl] = wstamps[wave][gl < 7 ? gl : 9];
 #endif
     // ---- store state in the reference's layout
+    const float sum_out = readlane_f(cs_, clane), dif_out = readlane_f(cd_, clane);
     if (gl == 0) {
-        cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum; cs.dif = dif; cs.buff[0] = 0.0f;
+        cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum_out; cs.dif = dif_out; cs.buff[0] = 0.0f;
         if (ext_lock < 0) {
             cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count; cs.sym_total = sym_total;
             if (counts) counts[chan] = nrec;

@@ -17,8 +17,8 @@ torch.cuda.synchronize()
 st = np.zeros((4096, 8), np.uint64)
 m.lib().m17gpu_debug_chan_stamps(st.ctypes.data_as(C.c_void_p))
 st = st[:min(4096, Cn)].astype(np.float64)
-tot = st[:, :6].sum(1)
-names = ["round top/tick", "FIR asm", "vote+commit of round", "syms out", "framer", "block head+tail (prefetch issue, x commit)", "rounds", "tap loads"]
+tot = st[:, :7].sum(1)
+names = ["round top/tick", "FIR asm", "vote+commit of round", "syms out", "framer", "block head+tail (x commit)", "tap loads (time)", "tap loads (count)"]
 print("per-wave time of the last step (ticks): min %.0f  median %.0f  p90 %.0f  max %.0f" % (tot.min(), np.median(tot), np.percentile(tot, 90), tot.max()))
 for i, n in enumerate(names):
-    print(f"  {n:45s} {st[:, i].mean() / nblk:10.1f} per block" + (f"  ({100 * st[:, i].sum() / tot.sum():.1f} %)" if i < 6 else ""))
+    print(f"  {n:45s} {st[:, i].mean() / nblk:10.1f} per block" + (f"  ({100 * st[:, i].sum() / tot.sum():.1f} %)" if i < 7 else ""))
