@@ -333,7 +333,7 @@ __device__ unsigned long long g_fe_span[16384][2];        // start / end s_memti
 #else
 #define FSTAMP(i) do {} while (0)
 #endif
-__global__ __launch_bounds__(64 * FQ_WAVES)
+__global__ __launch_bounds__(64 * FQ_WAVES, 4)
 void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
                   float *__restrict__ disc_raw, float *__restrict__ offs,
                   int nblk, int total, int update_state)

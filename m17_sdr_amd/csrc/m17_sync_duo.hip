@@ -135,39 +135,42 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                 // ---- timing recovery in rounds of 64 instants; x[i .. i+30] is the delay line at input i
                 const int thresh = lockv ? 80 : 10;
                 int p = 0, m_idx = 0;
-                while (p < kDiscOut) {
-                    if (clk == 1) {
-                        // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72)
-                        clk = 0;
-                        const float d0 = (sum < 0.0f) ? -dif : dif;
-                        if (d0 > 0.0f) thr++;
-                        if (d0 < 0.0f) thr--;
-                        if (thr > thresh) {
-                            index = (index + 1 == kPhases) ? 0 : index + 1; thr = 0;
-                            if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.H[(hp + m_idx) & (kDuoRing - 1)] = 0.0f; m_idx++; }
-                        }
-                        if (thr < -thresh) {
-                            thr = 0; index = (index == 0) ? kPhases - 1 : index - 1;
-                            if (index == kPhases - 1) { clk = 1; m_idx--; }
-                        }
-                        p++;
-                        continue;
+                // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72): the first input of a block
+                // whose predecessor ended on a filter instant, and the input behind a wrap of the branch
+                auto tick = [&]() {
+                    clk = 0;
+                    const float d0 = (sum < 0.0f) ? -dif : dif;
+                    if (d0 > 0.0f) thr++;
+                    if (d0 < 0.0f) thr--;
+                    if (thr > thresh) {
+                        index = (index + 1 == kPhases) ? 0 : index + 1; thr = 0;
+                        if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.H[(hp + m_idx) & (kDuoRing - 1)] = 0.0f; m_idx++; }
                     }
+                    if (thr < -thresh) {
+                        thr = 0; index = (index == 0) ? kPhases - 1 : index - 1;
+                        if (index == kPhases - 1) { clk = 1; m_idx--; }
+                    }
+                    p++;
+                };
+                while (clk == 1 && p < kDiscOut) tick();
+                while (p < kDiscOut) {
                     if (tap_index != index) {
                         const float4 *t4 = reinterpret_cast<const float4 *>(&taps[64 * index]);
 #pragma unroll
                         for (int q = 0; q < 16; ++q) tp[q] = t4[q];
                         tap_index = index;
                     }
-                    const int rem = (kDiscOut - p + 1) >> 1;          // filter instants left in the block
-                    const int nv = rem < LPC ? rem : LPC;
-                    const v2f a = fir_pair(my.x + p + 2 * (gl < nv ? gl : 0), tp);
+                    // lane g takes the instant at input p + 2g; near the end of the block the upper lanes run past it into
+                    // the ring that follows x[] in the channel's LDS, and nothing of theirs is used (k_sync_frame_wave)
+                    const v2f a = fir_pair(my.x + p + 2 * gl, tp);
                     const float s = a.x, d = a.y;
-                    const bool vote_ok = (gl < nv) && (p + 2 * gl + 1 < kDiscOut);
+                    const int rem = kDiscOut - p;                     // >= 1
+                    const int nv = min(LPC, (rem + 1) >> 1);          // filter instants of this round
+                    const int nvote = min(LPC, rem >> 1);             // ... whose vote tick p + 2g + 1 is inside the block
+                    const unsigned long long okm = (nvote >= 64) ? ~0ull : ((1ull << nvote) - 1ull);
                     const float dd = (s < 0.0f) ? -d : d;
-                    const bool up = vote_ok && dd > 0.0f, dn = vote_ok && dd < 0.0f;
-                    const unsigned long long um = __builtin_amdgcn_ballot_w64(up);
-                    const unsigned long long dm = __builtin_amdgcn_ballot_w64(dn);
+                    const unsigned long long um = __builtin_amdgcn_ballot_w64(dd > 0.0f) & okm;
+                    const unsigned long long dm = __builtin_amdgcn_ballot_w64(dd < 0.0f) & okm;
                     const int nu = (int)__popcll(um), nd = (int)__popcll(dm);
                     int naccept = nv, kl = -1, ts = 0;
                     // the counter can only leave [-thresh, thresh] in this round if all the votes of one sign could
@@ -175,8 +178,9 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                     if (uni(thr) + nu > thresh || uni(thr) - nd < -thresh) {
                         const int pu = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
                         const int pd = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0u));
-                        const int tk = thr + pu - pd + (int)up - (int)dn;
-                        const unsigned long long cr = __builtin_amdgcn_ballot_w64(vote_ok && (tk > thresh || tk < -thresh));
+                        const int own = (int)((um >> gl) & 1ull) - (int)((dm >> gl) & 1ull);
+                        const int tk = thr + pu - pd + own;
+                        const unsigned long long cr = __builtin_amdgcn_ballot_w64(tk > thresh || tk < -thresh) & okm;
                         if (cr) {
                             kl = (int)__builtin_ctzll(cr);
                             naccept = kl + 1;
@@ -198,11 +202,12 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                             if (index == kPhases - 1) { clk = 1; m_idx--; }
                         }
                         p = p + 2 * kl + 2;
+                        while (clk == 1 && p < kDiscOut) tick();       // a wrap: the next input is a vote tick again
                     } else {
                         thr += nu - nd;
-                        const int ilast = p + 2 * (nv - 1);
-                        if (ilast + 1 < kDiscOut) { clk = 0; p = ilast + 2; }
-                        else { clk = 1; p = kDiscOut; }
+                        p += 2 * nv;                                   // behind the last instant's vote tick ...
+                        clk = p > kDiscOut ? 1 : 0;                    // ... which falls into the next block when that instant is input 383
+                        p = min(p, kDiscOut);
                     }
                 }
                 n = m_idx > 0 ? m_idx : 0;
