@@ -12,7 +12,7 @@
 //   k_book_chan       a25 etc.   per-channel in-order LICH/LSF/packet bookkeeping          (m17_book.hip)
 //
 // Also here: the exact-arithmetic helpers with their exhaustive self tests, the sync correlator
-// (sync_check, sync_accept), the one-state-per-lane Viterbi (viterbi16) behind the stage entry
+// (SyncResult, sync_accept), the one-state-per-lane Viterbi (viterbi16) behind the stage entry
 // points k_viterbi / k_demap / k_golay, and k_reset.
 //
 // Numeric contract: IEEE binary32, no FMA contraction, no
@@ -565,44 +565,7 @@ __global__ void k_dc_remove(float *__restrict__ disc, const float *__restrict__ 
 // ---------------------------------------------------------------------------
 struct SyncResult { int type; int votes; float variance; };
 
-__device__ __forceinline__ SyncResult sync_check(const float v[8])
-{
-    // bit i set = template symbol i is -1 (sframe, m17_rx_frame.cpp:5-12);
-    // multiplying by +-1.0f is exact, so the running sums use add / subtract
-    constexpr unsigned neg[6] = M17_SYNC_NEG_MASKS;
-    float sums[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        float s = (neg[k] & 1u) ? -v[0] : v[0];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) s = (neg[k] >> i & 1u) ? s - v[i] : s + v[i];
-        sums[k] = s;
-    }
-    float mmin = fabsf(v[0]), mmax = mmin;
-#pragma unroll
-    for (int i = 1; i < 8; ++i) {
-        const float a = fabsf(v[i]);
-        if (a > mmax) mmax = a;
-        else if (a < mmin) mmin = a;
-    }
-    float var = (mmax - mmin) / mmax;
-    if (var != var) var = 1.0f;
-    float best = 0.0f; int nmax = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-        if (sums[k] > best) { best = sums[k]; nmax = k; }
-    unsigned nm = neg[0];
-#pragma unroll
-    for (int k = 1; k < 6; ++k) nm = (nmax == k) ? neg[k] : nm;
-    int votes = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const bool bad = (nm >> i & 1u) ? (v[i] > 0.0f) : (v[i] < 0.0f);
-        votes += bad ? 1 : 0;
-    }
-    SyncResult r; r.type = nmax; r.votes = votes; r.variance = var;
-    return r;
-}
+// (the check itself is sync_check_lanes8, m17_sync_common.hip: one frame head on a wave's lane groups of eight)
 
 // m17_unlocked_sync_check / m17_locked_sync_check (m17_rx_frame.cpp:82-103).
 // `variance < 0.3` compares against a double literal: (double)v < 0.3 <=> v < 0.3f

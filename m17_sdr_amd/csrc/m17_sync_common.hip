@@ -1,7 +1,8 @@
 // m17_sync_common.hip -- helpers shared by the timing/framer kernels (included by m17gpu_capi.hip
 // after m17_kernels.hip; same namespace): LDS-only barrier and wave fence, s_memtime phase stamps
-// of the instrumented build, frame-slot store, hunt pre-filter, the packed (matched, derivative) FIR with
-// the taps in VGPRs (two-wave kernel), the frame-sync check on lane groups of eight and the record writer.
+// of the instrumented build, frame-slot store, the packed (matched, derivative) FIR with
+// the taps in VGPRs (two-wave kernel), the frame-sync check on lane groups of eight, the unlocked framer's hunt pass
+// and the record writer.
 #pragma clang fp contract(off)
 
 // The hand-scheduled packed-FIR sequences here and in m17_fir_sgpr.inc place every v_pk_mul_f32 (op_sel) product two
@@ -77,25 +78,6 @@ __device__ __forceinline__ void store_frame_slot(float *__restrict__ fd, int typ
             if (q < kFrameSyms) *reinterpret_cast<float4 *>(fd + q) = t[r];
         }
     }
-}
-
-// candidate pre-filter of the sync hunt: m17_unlocked_sync_check needs votes == 0 for
-// the winning template, i.e. no symbol of the window may have the sign OPPOSITE to
-// that template (zeros and NaNs never vote, m17_rx_frame.cpp:77-80).  A window that
-// is incompatible with all four acceptable templates (types 1..4) cannot be accepted.
-__device__ __forceinline__ bool hunt_compatible(const float v[8])
-{
-    unsigned pos = 0, neg = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        pos |= (v[i] > 0.0f) ? (1u << i) : 0u;
-        neg |= (v[i] < 0.0f) ? (1u << i) : 0u;
-    }
-    constexpr unsigned tn[4] = {sync_neg_mask(1), sync_neg_mask(2), sync_neg_mask(3), sync_neg_mask(4)};     // bit i set: template symbol i is -1
-    bool ok = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ok = ok || (((pos & tn[k]) == 0u) && ((neg & (~tn[k] & 0xFFu)) == 0u));
-    return ok;
 }
 
 #ifdef M17_STAMPS
@@ -218,6 +200,45 @@ __device__ __forceinline__ SyncResult sync_check_lanes8(float vs, unsigned sgn)
     if (v0 != v0) var = 1.0f;
     r.variance = var;
     return r;
+}
+
+// One pass of the unlocked framer's hunt (m17_rx_sym, m17_rx_frame.cpp:155-171, over m17_unlocked_sync_check :92-103):
+// candidates are the block's symbols pos .. pos + 63 (those below n), the window of candidate j the eight symbols
+// j - 7 .. j; ld(i) returns symbol i of the block (i >= -7: the ring keeps what came before).  Returns the offset of
+// the first accepted candidate, with its check result in `out`, or -1.
+//   Pre-filter on sign bits: acceptance needs votes == 0 for the winning template, i.e. no symbol of the window with
+//   the sign OPPOSITE to it (zeros and NaNs never vote), and the winner must be one of types 1..4: a window that is
+//   incompatible with all four cannot be accepted.  Lane l loads ONE symbol; two ballots give the signs of the 71
+//   symbols as bit strings, the window of candidate c is bits c .. c + 7 of them.  In noise 1.6 % of the windows
+//   pass; those are checked exactly, one after the other in position order, by the lane-group check the locked
+//   framer uses -- instead of every lane loading its own eight symbols and the whole wave running the six-template
+//   check whenever one lane's window passes, which in noise is always.
+template <class Ld>
+__device__ __forceinline__ int hunt_pass(int pos, int n, int gl, Ld ld, SyncResult &out)
+{
+    const bool cand = pos + gl < n;
+    const float v = ld(cand ? pos + gl : pos);
+    const float t = ld(pos - 7 + (gl < 7 ? gl : 0));
+    const unsigned long long p64 = __builtin_amdgcn_ballot_w64(cand && v > 0.0f), n64 = __builtin_amdgcn_ballot_w64(cand && v < 0.0f);
+    const unsigned long long p7 = __builtin_amdgcn_ballot_w64(gl < 7 && t > 0.0f), n7 = __builtin_amdgcn_ballot_w64(gl < 7 && t < 0.0f);
+    // bit i of (hi : lo) = symbol pos - 7 + i
+    const unsigned long long plo = p7 | (p64 << 7), nlo = n7 | (n64 << 7);
+    const unsigned long long pmid = (plo >> 32) | ((p64 >> 57) << 32), nmid = (nlo >> 32) | ((n64 >> 57) << 32);   // bits 32 .. 95
+    const int sh = gl & 31;
+    const unsigned pw = (unsigned)((gl < 32 ? plo : pmid) >> sh) & 0xFFu, nw = (unsigned)((gl < 32 ? nlo : nmid) >> sh) & 0xFFu;
+    constexpr unsigned tn[4] = {sync_neg_mask(1), sync_neg_mask(2), sync_neg_mask(3), sync_neg_mask(4)};     // bit i set: template symbol i is -1
+    bool ok = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ok = ok || (((pw & tn[k]) | (nw & (~tn[k] & 0xFFu))) == 0u);
+    unsigned long long cm = __builtin_amdgcn_ballot_w64(cand && ok);
+    const unsigned sgn = sync_sign_mask(gl);
+    while (cm) {
+        const int l = (int)__builtin_ctzll(cm);
+        const SyncResult r = sync_check_lanes8(ld(pos + l - 7 + (gl & 7)), sgn);
+        if (sync_accept(r, false)) { out = r; return l; }
+        cm &= cm - 1ull;
+    }
+    return -1;
 }
 
 // one record: five words from scalars, eleven zero words, lanes 0..15

@@ -328,24 +328,14 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                     }
                 }
             } else {
-                // hunt: candidate symbol j = pos+gl, window = ring [hp+j-7, hp+j]
-                const int jc = pos + gl;
-                const bool cand = jc < n;
-                const int jj = cand ? jc : pos;
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = my.H[(hp + jj - 7 + i) & RM];
-                SyncResult r; r.type = 0; r.votes = 8; r.variance = 1.0f;
-                if (cand && hunt_compatible(v)) r = sync_check(v);           // most windows are rejected by sign
-                const unsigned long long hm = __builtin_amdgcn_ballot_w64(cand && sync_accept(r, false));
-                if (hm) {
-                    const int l = (int)__builtin_ctzll(hm);
+                // hunt: candidate symbol j = pos + lane, window = ring [hp + j - 7, hp + j]
+                SyncResult r;
+                const int l = hunt_pass(pos, n, gl, [&](int i) { return ring_ld(hp + i, hb); }, r);
+                if (l >= 0) {
                     const int js = pos + l;
                     // copy_sync(); m_fclk = 8; lock; m17_aos(): the window already is the head of the frame
                     fclk = 8; ferr = 0; flock = 1;
-                    const int ty = __builtin_amdgcn_readlane(r.type, l), vo = __builtin_amdgcn_readlane(r.votes, l);
-                    const float va = readlane_f(r.variance, l);
-                    emit_record_wave(crecs, rec_cap, nrec, gl, (uint32_t)ty | ((uint32_t)vo << 8), M17_F_AOS, va,
+                    emit_record_wave(crecs, rec_cap, nrec, gl, (uint32_t)r.type | ((uint32_t)r.votes << 8), M17_F_AOS, r.variance,
                                      block_count, (uint32_t)js);
                     nrec++;
                     pos = js + 1;
@@ -374,7 +364,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
 
 #ifdef M17_STAMPS
     WSTAMP(5);
-    if (chan < 4096 && gl < 8) g_chan_stamps[chan][gl] = wstamps[wave][gl < 7 ? gl : 9];
+    if (chan < 4096 && gl < 8) g_chan_stamps[chan][gl] = wstamps[wave][gl < 7 ? gl : 8];
 #endif
     // ---- store state in the reference's layout
     const float sum_out = readlane_f(cs_, clane), dif_out = readlane_f(cd_, clane);

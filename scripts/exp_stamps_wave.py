@@ -18,7 +18,10 @@ st = np.zeros((4096, 8), np.uint64)
 m.lib().m17gpu_debug_chan_stamps(st.ctypes.data_as(C.c_void_p))
 st = st[:min(4096, Cn)].astype(np.float64)
 tot = st[:, :7].sum(1)
-names = ["round top/tick", "FIR asm", "vote+commit of round", "syms out", "framer", "block head+tail (x commit)", "tap loads (time)", "tap loads (count)"]
+names = ["round top/tick", "FIR asm", "vote+commit of round", "syms out", "framer", "block head+tail (x commit)", "tap loads (time)", "rounds"]
 print("per-wave time of the last step (ticks): min %.0f  median %.0f  p90 %.0f  max %.0f" % (tot.min(), np.median(tot), np.percentile(tot, 90), tot.max()))
 for i, n in enumerate(names):
     print(f"  {n:45s} {st[:, i].mean() / nblk:10.1f} per block" + (f"  ({100 * st[:, i].sum() / tot.sum():.1f} %)" if i < 7 else ""))
+r = st[:, 7] / nblk
+print("rounds per block, by channel (this step): " + "  ".join(f"p{q} {np.percentile(r, q):.1f}" for q in (0, 10, 50, 90, 99, 100)))
+print("channels with more than 8 rounds per block: %d of %d; their share of all rounds: %.1f %%" % ((r > 8).sum(), len(r), 100 * r[r > 8].sum() / r.sum()))
