@@ -577,24 +577,6 @@ __device__ __forceinline__ bool sync_accept(const SyncResult &r, bool locked)
     return false;
 }
 
-// one 64-byte framer record, written by lanes 0..15 of the wave
-__device__ __forceinline__ void emit_record(m17gpu_rec_dev *recs, int rec_cap, int idx,
-                                            uint32_t w0, uint32_t w1, float var, uint32_t block, uint32_t sympos)
-{
-    if (idx >= rec_cap) return;
-    uint32_t *r = reinterpret_cast<uint32_t *>(&recs[idx]);
-    const int lane = lane_id();
-    if (lane < 16) {
-        uint32_t v = 0;
-        if (lane == 0) v = w0;
-        if (lane == 1) v = w1;
-        if (lane == 2) v = __float_as_uint(var);
-        if (lane == 3) v = block;
-        if (lane == 4) v = sympos;
-        r[lane] = v;
-    }
-}
-
 // ---------------------------------------------------------------------------
 // frame decode: 16 lanes per frame
 // ---------------------------------------------------------------------------
