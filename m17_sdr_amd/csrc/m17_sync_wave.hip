@@ -12,7 +12,7 @@
 //   * every control variable (m_clk, m_thr, m_index, the symbol count, lock, frame clock) is
 //     wave-uniform: SGPRs, scalar ALU, scalar branches; vote masks come straight out of v_cmp;
 //   * the 31 (matched, derivative) tap pairs of the current polyphase branch are 62 SGPRs, loaded
-//     with s_load from the constant table when the branch changes, and are the scalar operand of the
+//     with s_load from the constant table at the head of every round, and are the scalar operand of the
 //     packed multiplies: no tap VGPRs, no tap LDS;
 //   * what is left per lane is the 31-sample window and the accumulators: ~70 VGPRs and 3.7 KB of LDS
 //     per wave, i.e. 6-7 waves per SIMD, which is what hides the LDS and issue latency.
@@ -32,35 +32,23 @@ struct WvChan {                                // LDS of one channel: 4 KB, the 
 };
 static_assert(sizeof(WvChan) == 4096, "WvChan layout");
 
-// The current branch's 31 (matched, derivative) tap pairs live in s[40:101] for the whole kernel: the kernel is compiled
-// with amdgpu_num_sgpr(46), which keeps the register allocator below s40, and only the two asm blocks below touch the
-// range (left to the allocator, 31 live 64-bit scalars plus the control state overflowed the 102 SGPRs and were
-// spilled to VGPR lanes around every round: 218 spills).  Tap pair j is s[40+2j : 41+2j].
+// The filter statement below loads the current branch's 31 (matched, derivative) tap pairs into s[40:101] itself and
+// declares them clobbered: tap pair j is s[40+2j : 41+2j].  (Kept there for the whole kernel -- loaded only when the
+// branch changed, the allocator held below s40 with amdgpu_num_sgpr(46) -- the control state around the rounds lived
+// in VGPR lanes: 100+ spills; same-box A/B 0.294 -> 0.290 ms for the reload in every round.)
 #define M17_TAP_CLOBBERS "s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s50","s51","s52","s53","s54","s55", \
     "s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s68","s69","s70","s71","s72","s73","s74",   \
     "s75","s76","s77","s78","s79","s80","s81","s82","s83","s84","s85","s86","s87","s88","s89","s90","s91","s92","s93",   \
     "s94","s95","s96","s97","s98","s99","s100","s101"
-// 62 dwords of one row of DevTables.tap_pairs by scalar loads, waited for here: a branch change happens once per ~80
-// symbol instants at most, and the filter keeps the compiler's counted waits on its window reads
-__device__ __forceinline__ void load_taps_s(const float *row)
-{
-    asm volatile("s_load_dwordx16 s[40:55], %0, 0x0\n\t"
-                 "s_load_dwordx16 s[56:71], %0, 0x40\n\t"
-                 "s_load_dwordx16 s[72:87], %0, 0x80\n\t"
-                 "s_load_dwordx8 s[88:95], %0, 0xc0\n\t"
-                 "s_load_dwordx4 s[96:99], %0, 0xe0\n\t"
-                 "s_load_dwordx2 s[100:101], %0, 0xf0\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 :: "s"(row) : "memory", M17_TAP_CLOBBERS);
-}
 
 // rx_sync_filter (m17_rx_sync.cpp:25-31) for both filters as one packed (s, d) chain, ascending order, bare first
 // product, separate multiply and add, the tap pair as the scalar source operand of v_pk_mul_f32.  The whole round --
-// sixteen aligned 8-byte window reads, counted waits, 31 multiplies and 30 adds -- is ONE asm statement (text in
+// six scalar tap loads, sixteen aligned 8-byte window reads, one wait, 31 multiplies and 30 adds -- is ONE asm statement (text in
 // m17_fir_sgpr.inc, written by scripts/gen_fir_asm.py), so no compiler-visible register ever holds a window value
 // that is still in flight.  ds_read_b64 with lane stride 8 bytes covers 64 consecutive dwords per half-wave:
 // conflict-free, 2 LDS cycles each; the ds_read2_b32 form of the first version (lane stride 2 dwords, 32 banks:
 // 2-way conflicts, 8 cycles each) made the LDS pipe the limit of the kernel (~600 of its cycles per channel-block).
+//   row      : the branch's row of DevTables.tap_pairs
 //   lds_pair : LDS byte address of the aligned pair that holds the window's first sample (x[w & ~1])
 //   odd      : the window starts on the pair's second element (wave-uniform)
 #include "m17_fir_sgpr.inc"
@@ -68,11 +56,11 @@ __device__ __forceinline__ void load_taps_s(const float *row)
     [acc] "=&v"(acc), [p] "=&v"(P), [q] "=&v"(Q), [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3),        \
     [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6), [x7] "=&v"(x7), [x8] "=&v"(x8), [x9] "=&v"(x9), [x10] "=&v"(x10),   \
     [x11] "=&v"(x11), [x12] "=&v"(x12), [x13] "=&v"(x13), [x14] "=&v"(x14), [x15] "=&v"(x15)
-__device__ __forceinline__ v2f fir_window_s(unsigned lds_pair, bool odd)
+__device__ __forceinline__ v2f fir_window_s(const float *row, unsigned lds_pair, bool odd)
 {
     v2f acc, P, Q, x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
-    if (!odd) asm volatile(M17_FIR_SGPR_EVEN : M17_FIR_OPERANDS : [a] "v"(lds_pair) : "memory");
-    else      asm volatile(M17_FIR_SGPR_ODD : M17_FIR_OPERANDS : [a] "v"(lds_pair) : "memory");
+    if (!odd) asm volatile(M17_FIR_SGPR_EVEN : M17_FIR_OPERANDS : [a] "v"(lds_pair), [row] "s"(row) : "memory", M17_TAP_CLOBBERS);
+    else      asm volatile(M17_FIR_SGPR_ODD : M17_FIR_OPERANDS : [a] "v"(lds_pair), [row] "s"(row) : "memory", M17_TAP_CLOBBERS);
     return acc;
 }
 typedef const __attribute__((address_space(3))) float *lds_cfp;
@@ -114,7 +102,7 @@ __device__ __forceinline__ void store_frame_slot_wave(float *__restrict__ fd, in
 
 constexpr int WV_WAVES = 4;                    // channels (waves) per workgroup; the waves never synchronise
 
-__global__ __launch_bounds__(64 * WV_WAVES, 6) __attribute__((amdgpu_num_sgpr(46)))
+__global__ __launch_bounds__(64 * WV_WAVES, 6)
 void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                        const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
                        ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
@@ -164,7 +152,6 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
     float *sym_out = syms ? syms + (size_t)chan * M17_SYM_STRIDE(nblk) + sym_total : nullptr;
     wave_fence();
 
-    int tap_index = -1;                                      // the branch whose tap pairs are in s[40:101]
     const unsigned xb = (unsigned)uni((int)(unsigned)(uintptr_t)(lds_cfp)my.x);       // LDS byte address of x[]
     const int bend = b0 + bcount;
 #ifdef M17_STAMPS
@@ -206,18 +193,11 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
         while (clk == 1 && p < kDiscOut) tick();
         while (p < kDiscOut) {
             WCNT(8);
-            if (tap_index != index) {
-                WSTAMP(0);
-                load_taps_s(&c_tab.tap_pairs[index][0]);
-                tap_index = index;
-                WCNT(9);
-                WSTAMP(6);
-            }
             WSTAMP(0);
             // Lane g takes the instant at input p + 2g.  Near the end of the block the upper lanes run past it: their
             // windows read whatever follows x[] in LDS (reads beyond the allocation return zero), and nothing of theirs
             // is used -- no vote (okm), no symbol (naccept <= nv), no carried value.
-            const v2f a = fir_window_s(((unsigned)gl << 3) + (xb + ((unsigned)(p & ~1) << 2)), (p & 1) != 0);
+            const v2f a = fir_window_s(&c_tab.tap_pairs[index][0], ((unsigned)gl << 3) + (xb + ((unsigned)(p & ~1) << 2)), (p & 1) != 0);
             WSTAMP(1);
             const float s = a.x, d = a.y;
             const int rem = kDiscOut - p;                     // >= 1

@@ -22,7 +22,7 @@ m.lib().m17gpu_debug_chan_stamps(st.ctypes.data_as(C.c_void_p))
 st = st[:min(4096, Cn)].astype(np.float64)
 tot = st[:, :7].sum(1)
 print("per-wave ticks: mean %.0f; sum over the %d waves / 6144 wave slots = %.0f ticks" % (tot.mean(), len(tot), tot.sum() * (Cn / len(tot)) / 6144))
-names = ["round top/tick", "FIR asm", "vote+commit of round", "syms out", "framer", "block head+tail (x commit)", "tap loads (time)", "rounds"]
+names = ["round top/tick", "FIR asm", "vote+commit of round", "syms out", "framer", "block head+tail (x commit)", "(unused)", "rounds"]
 print("per-wave time of the last step (ticks): min %.0f  median %.0f  p90 %.0f  max %.0f" % (tot.min(), np.median(tot), np.percentile(tot, 90), tot.max()))
 for i, n in enumerate(names):
     print(f"  {n:45s} {st[:, i].mean() / nblk:10.1f} per block" + (f"  ({100 * st[:, i].sum() / tot.sum():.1f} %)" if i < 7 else ""))
