@@ -340,6 +340,8 @@ def fanout_legs(args, torch, dist, rx, out, iq_step, world, rank, backend, C, nb
     try:
         if os.environ.get("M17_BENCH_INJECT_FANOUT_FAILURE") == str(rank):           # test hook (tests/test_a_bench_ranks.py)
             raise RuntimeError("injected fan-out failure")
+        if os.environ.get("M17_BENCH_INJECT_FANOUT_HANG") == str(rank):              # test hook: a transfer that never returns
+            time.sleep(3600)
         if rank == 0:
             full = iq_step.repeat(world, 1, 1, 1) if world > 1 else iq_step         # content is irrelevant to the transfer
     except Exception as e:                                       # noqa: BLE001 -- reported in the line
@@ -433,11 +435,6 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    fan = None
-    if world > 1 and not args.no_fanout:
-        # after the timed region and outside `value`: a failure of the transfer legs must not cost the measurement
-        fan = fanout_legs(args, torch, dist, rx, out, iq[args.warmup % len(iq)], world, rank, backend, C, nblk, mode)
-
     syms = world * C * nblk * 192 * args.steps
     msym = syms / dt / 1e6
     ms_step = dt / args.steps * 1e3
@@ -462,6 +459,27 @@ def run_rank(args):
     }
     if args.option:
         line["config"]["options"] = list(args.option)
+    fan = None
+    if world > 1 and not args.no_fanout:
+        # After the timed region and outside `value`: neither a failure nor a HANG of the transfer legs may cost the
+        # measurement.  A collective that never returns cannot be cancelled, so a watchdog prints the line as it stands
+        # (rank 0) and ends the process on every rank when the legs overrun their allowance.
+        import threading
+        allowance = float(os.environ.get("M17_BENCH_FANOUT_TIMEOUT", "120"))
+
+        def overrun():
+            if rank == 0:
+                line["fanout"] = {"fanout_error": f"the transfer legs did not finish within {allowance:g} s; abandoned"}
+                line["cpu_baseline"] = None
+                sys.stdout.write(json.dumps(line) + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+
+        dog = threading.Timer(allowance, overrun)
+        dog.daemon = True
+        dog.start()
+        fan = fanout_legs(args, torch, dist, rx, out, iq[args.warmup % len(iq)], world, rank, backend, C, nblk, mode)
+        dog.cancel()
     if fan is not None:
         line["fanout"] = fan
     if fan is not None and "fanout_ms" in fan:

@@ -46,6 +46,21 @@ def test_bench_line_survives_a_failing_fanout_leg():
     assert "fanout_error" in line["fanout"] and "with_fanout" not in line
 
 
+def test_bench_line_survives_a_hanging_fanout_leg():
+    """A transfer leg that never returns on one rank (its peer then waits in the agreement all-reduce for ever) must
+    not cost the measurement either: the watchdog prints the line without the legs and ends every rank."""
+    env = dict(os.environ, M17_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4", M17_BENCH_INJECT_FANOUT_HANG="1",
+               M17_BENCH_FANOUT_TIMEOUT="8")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--channels", "64", "--blocks", "4", "--no-cpu-baseline", "--no-noisy"],
+                       env=env, capture_output=True, text=True, timeout=150)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert "did not finish" in line["fanout"]["fanout_error"] and "with_fanout" not in line
+
+
 def test_scatter_and_gather_with_device_tensors_over_rccl():
     """shard.scatter_iq / shard.gather_records with CUDA tensors on the nccl (= RCCL) backend.  One device is
     all a test box has, so the group has one rank: the calls, tensor placement and the record layout are the
