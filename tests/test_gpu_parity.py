@@ -453,7 +453,10 @@ def test_hostile_input_zero_saturated_and_noise():
     iq[6] = rng.integers(-32768, 32768, size=iq[6].shape, dtype=np.int16)
     iq[7] = rng.integers(-3, 4, size=iq[7].shape, dtype=np.int16)      # tiny amplitudes incl. (0,0)
     iq[8, 5, 100:130] = 0
+    iq[9, :3] = 12345                                     # a constant carrier (symbols exactly 0.0: the hunt's zero filter), then the signal
+    iq[10, 6:] = iq[10, 5, -1]                            # ... and the other way round
     _compare_raw(np.ascontiguousarray(iq), mode=1)
+    _compare_raw(np.ascontiguousarray(iq), mode=1, options={"sync_impl": 7})
     _compare_raw(np.ascontiguousarray(iq), mode=0, options={"sync_impl": 7})
 
 
