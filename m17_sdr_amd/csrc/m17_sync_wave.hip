@@ -26,9 +26,10 @@ namespace m17dev {
 constexpr int kWvRing = 512;                   // 191 (frame in progress) + 193 (block being written) < 512
 
 struct WvChan {                                // LDS of one channel: 4 KB, the ring 2 KB-aligned (ring addresses by AND/OR)
-    float H[kWvRing];                          // symbol ring
     float x[kTaps - 1 + kDiscOut + 2];         // delay-line history (30) + this block's 384 inputs
     float pad[1024 - kWvRing - (kTaps - 1 + kDiscOut + 2)];
+    float H[kWvRing];                          // symbol ring; it follows x[]: the last round of a block reads up to 124 floats
+                                               // past x[] (lanes whose instants lie beyond the block; nothing of theirs is used)
 };
 static_assert(sizeof(WvChan) == 4096, "WvChan layout");
 
@@ -195,8 +196,8 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
             WCNT(8);
             WSTAMP(0);
             // Lane g takes the instant at input p + 2g.  Near the end of the block the upper lanes run past it: their
-            // windows read whatever follows x[] in LDS (reads beyond the allocation return zero), and nothing of theirs
-            // is used -- no vote (okm), no symbol (naccept <= nv), no carried value.
+            // windows read what follows x[] in the channel's LDS (padding and the head of the ring), and nothing of
+            // theirs is used -- no vote (okm), no symbol (naccept <= nv), no carried value.
             const v2f a = fir_window_s(&c_tab.tap_pairs[index][0], ((unsigned)gl << 3) + (xb + ((unsigned)(p & ~1) << 2)), (p & 1) != 0);
             WSTAMP(1);
             const float s = a.x, d = a.y;
