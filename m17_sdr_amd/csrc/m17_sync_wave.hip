@@ -33,14 +33,14 @@ struct WvChan {                                // LDS of one channel: 4 KB, the 
 };
 static_assert(sizeof(WvChan) == 4096, "WvChan layout");
 
-// The filter statement below loads the current branch's 31 (matched, derivative) tap pairs into s[40:101] itself and
-// declares them clobbered: tap pair j is s[40+2j : 41+2j].  (Kept there for the whole kernel -- loaded only when the
+// The filter statement below loads the current branch's 31 (matched, derivative) tap pairs into s[36:97] itself and
+// declares them clobbered: tap pair j is s[36+2j : 37+2j].  (Kept there for the whole kernel -- loaded only when the
 // branch changed, the allocator held below s40 with amdgpu_num_sgpr(46) -- the control state around the rounds lived
 // in VGPR lanes: 100+ spills; same-box A/B 0.294 -> 0.290 ms for the reload in every round.)
-#define M17_TAP_CLOBBERS "s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s50","s51","s52","s53","s54","s55", \
-    "s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s68","s69","s70","s71","s72","s73","s74",   \
-    "s75","s76","s77","s78","s79","s80","s81","s82","s83","s84","s85","s86","s87","s88","s89","s90","s91","s92","s93",   \
-    "s94","s95","s96","s97","s98","s99","s100","s101"
+#define M17_TAP_CLOBBERS "s36","s37","s38","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s50", \
+    "s51","s52","s53","s54","s55","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s68","s69", \
+    "s70","s71","s72","s73","s74","s75","s76","s77","s78","s79","s80","s81","s82","s83","s84","s85","s86","s87","s88", \
+    "s89","s90","s91","s92","s93","s94","s95","s96","s97"
 
 // rx_sync_filter (m17_rx_sync.cpp:25-31) for both filters as one packed (s, d) chain, ascending order, bare first
 // product, separate multiply and add, the tap pair as the scalar source operand of v_pk_mul_f32.  The whole round --
