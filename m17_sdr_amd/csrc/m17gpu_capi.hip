@@ -518,6 +518,7 @@ int m17gpu_parse_lsf_batch(m17gpu_ctx *ctx, const uint8_t *d_lsf, m17gpu_lsf_fie
 // is taken from the process (the copy the host application or PyTorch already loaded, else librccl.so.1) at first
 // use: the library itself does not link it, so single-GPU users need no RCCL at all.
 // ---------------------------------------------------------------------------------------------------------------
+} // extern "C" (the helper below has C++ linkage)
 namespace {
 struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
@@ -554,6 +555,7 @@ const RcclApi &rccl()
             return fail(M17GPU_ERR_HIP, std::string(#expr) + ": " + (R.GetErrorString ? R.GetErrorString(r_) : "RCCL error")); \
     } while (0)
 } // namespace
+extern "C" {
 
 void m17gpu_shard_range(int rank, int world, int n_channels, int *lo, int *hi)
 {
