@@ -117,6 +117,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
         wave_fence();
         float4 tp[16];                                                // 32 tap pairs of the current branch, kept across blocks
         int tap_index = -1;
+        bool calm = false, crossed = false;                           // the last block / this block saw a branch step
         for (int b = b0; b < bend; ++b) {
             // next block's input: loads issued now, committed at the end of the block
             constexpr int PF = kDiscOut / LPC;
@@ -135,6 +136,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                 // ---- timing recovery in rounds of 64 instants; x[i .. i+30] is the delay line at input i
                 const int thresh = lockv ? 80 : 10;
                 int p = 0, m_idx = 0;
+                crossed = false;
                 // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72): the first input of a block
                 // whose predecessor ended on a filter instant, and the input behind a wrap of the branch
                 auto tick = [&]() {
@@ -143,16 +145,61 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                     if (d0 > 0.0f) thr++;
                     if (d0 < 0.0f) thr--;
                     if (thr > thresh) {
-                        index = (index + 1 == kPhases) ? 0 : index + 1; thr = 0;
+                        index = (index + 1 == kPhases) ? 0 : index + 1; thr = 0; crossed = true;
                         if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.H[(hp + m_idx) & (kDuoRing - 1)] = 0.0f; m_idx++; }
                     }
                     if (thr < -thresh) {
-                        thr = 0; index = (index == 0) ? kPhases - 1 : index - 1;
+                        thr = 0; index = (index == 0) ? kPhases - 1 : index - 1; crossed = true;
                         if (index == kPhases - 1) { clk = 1; m_idx--; }
                     }
                     p++;
                 };
                 while (clk == 1 && p < kDiscOut) tick();
+                // A calm block at once.  When the previous block went by without a branch step, the loop most likely
+                // sits on its branch for this one too: its three rounds are filtered back to back -- symbols stored as
+                // they come, only the vote counts kept -- and committed together if the counter stays inside
+                // [-thresh, thresh] throughout (per round the two scalar compares of the rounds below, the per-tick counts
+                // only if those leave a doubt).  If it does not, nothing has happened yet: the rounds below start over
+                // from the block's first instant and overwrite the symbols.  (This wave is alone on its SIMD slot: what it
+                // saves in instructions it saves in time; k_sync_frame_wave, bound otherwise, loses with the same path.)
+                if (calm && p <= 1 && m_idx == 0) {
+                    if (tap_index != index) {
+                        const float4 *t4 = reinterpret_cast<const float4 *>(&taps[64 * index]);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) tp[q] = t4[q];
+                        tap_index = index;
+                    }
+                    int t = thr;
+                    bool ok = true;
+                    v2f a = {0.0f, 0.0f};
+#pragma unroll 1
+                    for (int r = 0; r < 3 && ok; ++r) {
+                        a = fir_pair(my.x + p + 128 * r + 2 * gl, tp);
+                        const float dd = (a.x < 0.0f) ? -a.y : a.y;
+                        // with the instants on the odd inputs, the vote of input 383's instant is cast in the next block
+                        const unsigned long long okm = (r == 2 && p != 0) ? 0x7FFFFFFFFFFFFFFFull : ~0ull;
+                        const unsigned long long um = __builtin_amdgcn_ballot_w64(dd > 0.0f) & okm;
+                        const unsigned long long dm = __builtin_amdgcn_ballot_w64(dd < 0.0f) & okm;
+                        const int nu = (int)__popcll(um), nd = (int)__popcll(dm);
+                        if (t + nu > thresh || t - nd < -thresh) {
+                            const int pu = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+                            const int pd = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0u));
+                            const int own = (int)((um >> gl) & 1ull) - (int)((dm >> gl) & 1ull);
+                            const int tk = t + pu - pd + own;
+                            if (__builtin_amdgcn_ballot_w64(tk > thresh || tk < -thresh) & okm) ok = false;
+                        }
+                        t += nu - nd;
+                        my.H[(hp + 64 * r + gl) & (kDuoRing - 1)] = a.x;
+                    }
+                    if (ok) {
+                        thr = t;
+                        m_idx = kFrameSyms;
+                        sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a.x), 63));
+                        dif = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a.y), 63));
+                        clk = p;                                      // odd inputs: the last vote tick falls into the next block
+                        p = kDiscOut;
+                    }
+                }
                 while (p < kDiscOut) {
                     if (tap_index != index) {
                         const float4 *t4 = reinterpret_cast<const float4 *>(&taps[64 * index]);
@@ -193,7 +240,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                     sum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), uni(naccept - 1)));
                     dif = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), uni(naccept - 1)));
                     if (kl >= 0) {
-                        thr = 0; clk = 0;
+                        thr = 0; clk = 0; crossed = true;
                         if (ts > thresh) {
                             index = (index + 1 == kPhases) ? 0 : index + 1;
                             if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.H[(hp + m_idx) & (kDuoRing - 1)] = 0.0f; m_idx++; }
@@ -224,6 +271,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                 clk = s_clk; thr = s_thr; index = s_index; sum = s_sum; dif = s_dif;
             }
             known_lock = lockv;
+            calm = !crossed;
             if (gl == 0) my.nsym[b & 3] = n;
             duo_post_lds(tim_blk, b - b0 + 1, gl);
             hp += n;
