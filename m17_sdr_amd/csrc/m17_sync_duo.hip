@@ -260,7 +260,17 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                 n = m_idx > 0 ? m_idx : 0;
                 // ---- the lock flag this block should have seen: after the framer of block b-1
                 int actual = known_lock;
+#ifdef M17_STAMPS
+                const unsigned long long before_ = acc_[0];
+#endif
                 STAMP(0);
+#ifdef M17_STAMPS
+                // per-block work of the first 64 channels' timing waves (scripts/exp_stamps_duo.py)
+                if (chan < 64 && gl == 0 && b - b0 < 64) {
+                    g_chan_stamps[chan * 64 + b - b0][6] = acc_[0] - before_;
+                    g_chan_stamps[chan * 64 + b - b0][7] = (unsigned long long)(calm ? 1 : 0) | ((unsigned long long)(crossed ? 1 : 0) << 1) | ((unsigned long long)lockv << 2);
+                }
+#endif
                 if (b > b0) {
                     duo_wait_lds(frm_blk, b - b0);
                     STAMP(1);
@@ -290,6 +300,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
         }
 #ifdef M17_STAMPS
         if (chan == 0 && gl == 0) { g_stamps[0] = acc_[0]; g_stamps[1] = acc_[1]; }
+        if (chan < 4096 && gl == 0) { g_chan_stamps[chan][5] = acc_[0]; g_chan_stamps[chan][4] = acc_[1]; }
 #endif
         if (gl == 0) { cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum; cs.dif = dif; cs.buff[0] = 0.0f; }
         for (int q = gl; q < kTaps - 1; q += LPC) cs.buff[q + 1] = my.x[q];
