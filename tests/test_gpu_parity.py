@@ -804,3 +804,46 @@ def test_parse_lsf_batch_matches_host_parser():
     oracle.L().m17o_decode_call(C.c_uint64(0x00102C8DA29F), buf)
     assert bytes(got[40, 26:35]) == buf.value == b"G4GUO/P  "       # src_call of the first KAT row
     rx.close()
+
+
+def test_a_call_can_be_captured_in_a_hip_graph_and_replayed():
+    """m17gpu_rx_blocks enqueues everything on the caller's stream and allocates nothing: a caller may capture a call
+    in a HIP graph (here through torch.cuda.CUDAGraph) and replay it on new input in the same buffers.  The replays must
+    give what plain calls give on the same stream of blocks, state carried from call to call included."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    C, nblk, T = 200, 6, 5
+    sig = m.generate_batch(C, nblk * T, n_stream_frames=12, ebn0_db=14.0)
+    slabs = [torch.from_numpy(np.ascontiguousarray(sig["iq"][:, k * nblk:(k + 1) * nblk])).cuda() for k in range(T)]
+
+    def run(graph):
+        rx = m.Receiver(C, nblk)
+        out = rx.alloc_outputs(nblk, want_syms=True)
+        stage = torch.empty_like(slabs[0])
+        got = []
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            stage.copy_(slabs[0]); rx.rx_blocks(stage, 1, out)              # the first call plain in both runs
+            torch.cuda.synchronize()
+            got.append((out["recs"].clone(), out["counts"].clone(), out["syms"].clone()))
+            g = None
+            if graph:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):                         # captured, not executed: the state stays as it is
+                    rx.rx_blocks(stage, 1, out)
+            for k in range(1, T):
+                stage.copy_(slabs[k])
+                if g is not None:
+                    g.replay()
+                else:
+                    rx.rx_blocks(stage, 1, out)
+                torch.cuda.synchronize()
+                got.append((out["recs"].clone(), out["counts"].clone(), out["syms"].clone()))
+        rx.close()
+        return got
+
+    plain, replayed = run(False), run(True)
+    for a, b in zip(plain, replayed):
+        assert torch.equal(a[1], b[1])
+        assert torch.equal(a[0], b[0])
+        assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
