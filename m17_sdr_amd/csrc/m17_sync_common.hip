@@ -208,10 +208,11 @@ __device__ __forceinline__ SyncResult sync_check_lanes8(float vs, unsigned sgn)
 // the first accepted candidate, with its check result in `out`, or -1.
 //   Pre-filter on sign bits: acceptance needs votes == 0 for the winning template, i.e. no symbol of the window with
 //   the sign OPPOSITE to it (zeros and NaNs never vote), and the winner must be one of types 1..4: a window that is
-//   incompatible with all four cannot be accepted; nor can one that holds an exact zero (find_variance then returns
-//   1 or NaN -> 1, never < 0.3) -- without that test a stretch of zeros, compatible with everything, would send every
-//   candidate to the exact check.  Lane l loads ONE symbol; three ballots give the signs and zeros of the 71
-//   symbols as bit strings, the window of candidate c is bits c .. c + 7 of them.  In noise 1.6 % of the windows
+//   incompatible with all four cannot be accepted.  Nor can one that holds a symbol WITHOUT a sign: an exact zero
+//   (find_variance then returns 1, or NaN -> 1, never < 0.3) or a NaN (every template sum is NaN, no sum beats 0, the
+//   type stays 0) -- without that test a squelched channel, whose symbols are all zeros or NaNs and compatible with
+//   everything, would send every candidate to the exact check.  Lane l loads ONE symbol; two ballots give the signs
+//   of the 71 symbols as bit strings, the window of candidate c is bits c .. c + 7 of them.  In noise 1.6 % of the windows
 //   pass; those are checked exactly, one after the other in position order, by the lane-group check the locked
 //   framer uses -- instead of every lane loading its own eight symbols and the whole wave running the six-template
 //   check whenever one lane's window passes, which in noise is always.
@@ -223,19 +224,16 @@ __device__ __forceinline__ int hunt_pass(int pos, int n, int gl, Ld ld, SyncResu
     const float t = ld(pos - 7 + (gl < 7 ? gl : 0));
     const unsigned long long p64 = __builtin_amdgcn_ballot_w64(cand && v > 0.0f), n64 = __builtin_amdgcn_ballot_w64(cand && v < 0.0f);
     const unsigned long long p7 = __builtin_amdgcn_ballot_w64(gl < 7 && t > 0.0f), n7 = __builtin_amdgcn_ballot_w64(gl < 7 && t < 0.0f);
-    const unsigned long long z64 = __builtin_amdgcn_ballot_w64(cand && v == 0.0f), z7 = __builtin_amdgcn_ballot_w64(gl < 7 && t == 0.0f);
     // bit i of (hi : lo) = symbol pos - 7 + i
-    const unsigned long long plo = p7 | (p64 << 7), nlo = n7 | (n64 << 7), zlo = z7 | (z64 << 7);
+    const unsigned long long plo = p7 | (p64 << 7), nlo = n7 | (n64 << 7);
     const unsigned long long pmid = (plo >> 32) | ((p64 >> 57) << 32), nmid = (nlo >> 32) | ((n64 >> 57) << 32);   // bits 32 .. 95
-    const unsigned long long zmid = (zlo >> 32) | ((z64 >> 57) << 32);
     const int sh = gl & 31;
     const unsigned pw = (unsigned)((gl < 32 ? plo : pmid) >> sh) & 0xFFu, nw = (unsigned)((gl < 32 ? nlo : nmid) >> sh) & 0xFFu;
-    const unsigned zw = (unsigned)((gl < 32 ? zlo : zmid) >> sh) & 0xFFu;
     constexpr unsigned tn[4] = {sync_neg_mask(1), sync_neg_mask(2), sync_neg_mask(3), sync_neg_mask(4)};     // bit i set: template symbol i is -1
     bool ok = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) ok = ok || (((pw & tn[k]) | (nw & (~tn[k] & 0xFFu))) == 0u);
-    unsigned long long cm = __builtin_amdgcn_ballot_w64(cand && ok && zw == 0u);
+    unsigned long long cm = __builtin_amdgcn_ballot_w64(cand && ok && (pw | nw) == 0xFFu);
     const unsigned sgn = sync_sign_mask(gl);
     while (cm) {
         const int l = (int)__builtin_ctzll(cm);

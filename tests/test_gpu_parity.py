@@ -847,3 +847,32 @@ def test_a_call_can_be_captured_in_a_hip_graph_and_replayed():
         assert torch.equal(a[1], b[1])
         assert torch.equal(a[0], b[0])
         assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
+
+
+def test_squelched_channels_do_not_slow_the_timing_stage():
+    """All-zero IQ limits to NaN and a constant carrier demodulates to exact zeros: every 8-symbol window of such a channel
+    is compatible with every sync template by sign.  The hunt must reject them before the exact check (a window with a
+    sign-less symbol cannot be accepted), or a squelched channel costs its wave many times a live one's and sets the
+    kernel's tail (4.2 ms against 0.27 ms at 16,384 channels when it did not).  Results are compared with the oracle in
+    test_hostile_input_zero_saturated_and_noise; this is the time."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    C, nblk = 4096, 12
+    gen = m.Receiver(C, nblk)
+    sig = gen.gen_batch(nblk * 2)["iq"][:, nblk:].contiguous()
+    gen.close()
+    times = {}
+    for name, iq in (("signal", sig), ("zeros", torch.zeros_like(sig)), ("carrier", torch.full_like(sig, 12345))):
+        rx = m.Receiver(C, nblk)
+        out = rx.alloc_outputs(nblk)
+        for _ in range(2):
+            rx.rx_blocks(iq, 1, out)
+        torch.cuda.synchronize()
+        rx.set_profiling(True)
+        for _ in range(4):
+            rx.rx_blocks(iq, 1, out)
+        torch.cuda.synchronize()
+        times[name] = rx.kernel_ms()[0][1]
+        rx.close()
+    assert times["zeros"] < 2.0 * times["signal"], times
+    assert times["carrier"] < 2.0 * times["signal"], times
