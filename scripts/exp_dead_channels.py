@@ -9,7 +9,13 @@ C, nblk = 16384, 12
 gen = m.Receiver(C, nblk)
 sig = gen.gen_batch(nblk * 3)["iq"][:, nblk:2 * nblk].contiguous()
 gen.close()
-for name, iq in (("signal", sig), ("all-zero IQ", torch.zeros_like(sig)), ("constant carrier", torch.full_like(sig, 12345))):
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+noise = torch.randint(-32768, 32768, sig.shape, generator=g, device="cuda", dtype=torch.int32).to(torch.int16)
+tiny = torch.randint(-3, 4, sig.shape, generator=g, device="cuda", dtype=torch.int32).to(torch.int16)
+alt = torch.empty_like(sig); alt[:, :, 0::2] = 32767; alt[:, :, 1::2] = -32768
+half = sig.clone(); half[::2] = 0                                     # every other channel squelched
+for name, iq in (("signal", sig), ("all-zero IQ", torch.zeros_like(sig)), ("constant carrier", torch.full_like(sig, 12345)),
+                 ("full-scale white noise", noise), ("+-3 LSB noise", tiny), ("alternating extremes", alt), ("every other channel squelched", half)):
     rx = m.Receiver(C, nblk)
     out = rx.alloc_outputs(nblk)
     for k in range(2): rx.rx_blocks(iq, 1, out)
