@@ -1,11 +1,11 @@
 """Timing stage on squelched input: all-zero IQ (symbols NaN) and a constant carrier (symbols exactly 0.0) against the
-normal signal, 16,384 x 12:   python scripts/exp_dead_channels.py [LIBNAME]"""
+normal signal:   python scripts/exp_dead_channels.py [LIBNAME [C nblk]]   (default 16,384 x 12)"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import m17_sdr_amd._lib as L
 if len(sys.argv) > 1: L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), sys.argv[1])
 import m17_sdr_amd as m
-C, nblk = 16384, 12
+C, nblk = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (16384, 12)
 gen = m.Receiver(C, nblk)
 sig = gen.gen_batch(nblk * 3)["iq"][:, nblk:2 * nblk].contiguous()
 gen.close()
