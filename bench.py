@@ -71,7 +71,7 @@ def parse_args(argv=None):
 # ------------------------------------------------------------------------------------------------
 # parent: start one process per GPU (never touches HIP itself)
 # ------------------------------------------------------------------------------------------------
-def launch_ranks(args, timeout_s=1500.0):
+def launch_ranks(args, timeout_s=1200.0):
     """Start one fresh child per rank (never a re-exec: this process has not touched the GPU and never does), poll
     them all, and on the first non-zero exit -- or after timeout_s -- terminate the others instead of leaving them in
     a rendezvous or a barrier until the process-group timeout."""
@@ -145,7 +145,8 @@ def make_input(args, rank, torch, rx, C, nblk, T):
         torch.cuda.empty_cache()
         steps = [slabs[k % Tg] for k in range(T)]
         w = min(args.warmup, Tg - 1)
-        return steps, {"iq": steps[w][:min(256, C)].cpu().numpy()}, Tg
+        nhost = min(C, max(256, 4 * host_cores()[0]))          # cpu_baseline: >= 4 channels per usable host thread
+        return steps, {"iq": steps[w][:nhost].cpu().numpy()}, Tg
     uniq = min(args.unique, C)
     nthreads = max(1, min(16, (os.cpu_count() or 8) // max(1, args.gpus)))
     sig = m.generate_batch(uniq, nblk, n_stream_frames=40, ebn0_db=args.ebn0,
@@ -158,23 +159,35 @@ def make_input(args, rank, torch, rx, C, nblk, T):
     return [dev] * T, sig, 1
 
 
-def cpu_baseline(mode, sig):
-    """The CPU oracle (port of the reference path) on a bounded sample of the same workload, all host
-    threads of this job's share, same run."""
-    from tests import oracle
-    avail, phys, smt = host_cores()
-    cores = max(1, min(avail, 16))          # the GPU box gives one GPU's job a share of 16 host threads
-    nch = sig["iq"].shape[0]
-    iq = np.ascontiguousarray(sig["iq"][:nch])
+def _time_oracle(oracle, iq, mode, threads, budget_s):
+    """Passes of the oracle over `iq` on `threads` OpenMP threads for about budget_s seconds: (symbols, seconds, passes)."""
+    nch = iq.shape[0]
     ch = oracle.Channels(nch)
-    ch.rx_blocks(iq, mode=mode, want_syms=False, nthreads=cores)      # warm (tables, page faults)
+    ch.rx_blocks(iq, mode=mode, want_syms=False, nthreads=threads)      # warm (tables, page faults, thread pool)
     reps, t_used = 0, 0.0
     t0 = time.perf_counter()
-    while t_used < 1.5 and reps < 2000:            # ~24 core-seconds on 16 threads
-        ch.rx_blocks(iq, mode=mode, want_syms=False, nthreads=cores)
+    while t_used < budget_s and reps < 4000:
+        ch.rx_blocks(iq, mode=mode, want_syms=False, nthreads=threads)
         reps += 1
         t_used = time.perf_counter() - t0
-    syms = nch * iq.shape[1] * 192 * reps
+    return nch * iq.shape[1] * 192 * reps, t_used, reps
+
+
+def cpu_baseline(mode, sig):
+    """The CPU oracle (port of the reference path, m17_dsp.cpp:461-476 call tree) on a bounded sample of the same
+    workload, on EVERY host thread this job may use (sched_getaffinity), same run; the figure on 16 threads -- what
+    earlier rounds reported -- rides along as `at_16_threads`."""
+    from tests import oracle
+    avail, phys, smt = host_cores()
+    cores = max(1, avail)
+    nch = min(sig["iq"].shape[0], max(256, 4 * cores))
+    iq = np.ascontiguousarray(sig["iq"][:nch])
+    syms, t_used, reps = _time_oracle(oracle, iq, mode, cores, 1.5)
+    at16 = None
+    if cores > 16:
+        s16, t16, r16 = _time_oracle(oracle, iq[:min(nch, 256)], mode, 16, 1.0)
+        at16 = {"value": round(s16 / t16 / 1e6, 3), "unit": "Msym/s", "cores": 16,
+                "sample": f"{min(nch, 256)} channels x {iq.shape[1]} blocks x {r16} passes ({t16:.2f} s wall)"}
     ch1 = oracle.Channels(1)                        # single-thread figure, to set beside SURVEY's 47.8 us/block
     t1 = time.perf_counter()
     for _ in range(8):
@@ -182,10 +195,11 @@ def cpu_baseline(mode, sig):
     us_blk = (time.perf_counter() - t1) / (8 * iq.shape[1]) * 1e6
     return {"value": round(syms / t_used / 1e6, 3), "unit": "Msym/s", "cores": cores, "kind": "port",
             "host": {"threads_usable_by_this_job": avail, "physical_cores": phys, "hardware_threads": smt,
-                     "note": "cores = OpenMP threads used; with SMT two of them may share a physical core"},
-            "sample": f"{nch} channels x {iq.shape[1]} blocks x {reps} passes of the same synthetic IQ, "
-                      f"{'full chain' if mode == 1 else 'front end'}, OpenMP over channels ({t_used:.2f} s wall); "
-                      f"1 thread: {us_blk:.1f} us/block",
+                     "note": "cores = OpenMP threads used = every thread sched_getaffinity grants; with SMT two of them share a physical core"},
+            "sample": f"{nch} channels ({nch / cores:.1f} per thread) x {iq.shape[1]} blocks x {reps} passes of the same synthetic IQ, "
+                      f"{'full chain' if mode == 1 else 'front end'}, OpenMP over channels ({t_used:.2f} s wall, "
+                      f"{t_used * cores:.0f} thread-seconds); 1 thread: {us_blk:.1f} us/block",
+            "at_16_threads": at16,
             "realtime_channels": int(syms / t_used / 4800)}
 
 
@@ -219,16 +233,21 @@ def roofline_obj(kms, ncalls, mode, cb_per_launch, key):
             "calls_timed": ncalls}
 
 
-def fir_stage(args, torch, device):
-    """BASELINE configs[1] in the same run: 1,024 channels x 50 blocks, front end only (limiter /
-    discriminator + polyphase RRC timing recovery + sync correlator), one continuous stream per channel."""
+def fir_stage(args, torch, device, C=1024, nblk=50, steps=30, warm=3):
+    """The FIR stage alone in the same run -- limiter / discriminator + polyphase RRC timing recovery + sync correlator,
+    symbols out (mode 0), one continuous stream per channel -- at BASELINE configs[1]'s own size (1,024 channels x 50
+    blocks) and, as `fir_stage_16384`, at the size north_star attaches its 40 %-of-HBM target to (>= 10,000 channels:
+    16,384 x 12, the headline's per-GPU batch)."""
     import m17_sdr_amd as m
-    C, nblk, steps, warm = 1024, 50, 30, 3
     rx = m.Receiver(C, nblk, device=device)
+    for kv in args.option:
+        name, value = kv.split("=")
+        rx.set_option(name, int(value))
     T = steps + warm
     big = rx.gen_batch(nblk * T, n_stream_frames=40, ebn0_db=200.0)["iq"]
     torch.cuda.synchronize(device)
-    slabs = big.view(C, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4).contiguous()
+    slabs = torch.empty((T, C, nblk, 1920, 2), dtype=torch.int16, device=big.device)
+    slabs.copy_(big.view(C, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4))
     del big
     out = rx.alloc_outputs(nblk, want_syms=True)
     for k in range(warm):
@@ -246,7 +265,8 @@ def fir_stage(args, torch, device):
     del slabs
     torch.cuda.empty_cache()
     ro = roofline_obj(kms, ncalls, 0, C * nblk, f"frontend:{C}x{nblk}")
-    return {"workload": "BASELINE configs[1]: 1,024 channels x 50 blocks, RRC FIR + timing recovery + sync correlator only",
+    what = "BASELINE configs[1]" if (C, nblk) == (1024, 50) else "the FIR stage at the headline's per-GPU batch"
+    return {"workload": f"{what}: {C:,} channels x {nblk} blocks, RRC FIR + timing recovery + sync correlator only",
             "ms": round(dt / steps * 1e3, 4), "value": round(C * nblk * 192 * steps / dt / 1e6, 3), "unit": "Msym/s",
             "frac": ro["frac"], "achieved": ro["achieved"], "traffic": ro["traffic"], "avg_ms": ro["avg_ms"],
             "kernel_sum_ms": ro["kernel_sum_ms"], "algorithmic_bytes_per_channel_block": BYTES_FRONT,
@@ -478,7 +498,10 @@ def run_rank(args):
         dog = threading.Timer(allowance, overrun)
         dog.daemon = True
         dog.start()
-        fan = fanout_legs(args, torch, dist, rx, out, iq[args.warmup % len(iq)], world, rank, backend, C, nblk, mode)
+        try:
+            fan = fanout_legs(args, torch, dist, rx, out, iq[args.warmup % len(iq)], world, rank, backend, C, nblk, mode)
+        except Exception as e:                                   # noqa: BLE001 -- a dead peer, a failed barrier: reported, the line survives
+            fan = {"fanout_error": f"{type(e).__name__}: {e}"[:300]}
         dog.cancel()
     if fan is not None:
         line["fanout"] = fan
@@ -494,6 +517,7 @@ def run_rank(args):
             line["noisy"] = noisy_leg(args, torch, local, C, nblk)
         if world == 1 and not args.no_fir_stage and mode == 1:
             line["fir_stage"] = fir_stage(args, torch, local)
+            line["fir_stage_16384"] = fir_stage(args, torch, local, C=16384, nblk=12, steps=20, warm=3)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mode, sig)
         else:

@@ -146,9 +146,6 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  *                            the filter taps in SGPRs beyond; 7 = that kernel at every size
  *   "fe_impl"            0 = by size (default), 1 = lane per channel-block, 2 = four lanes per
  *                            channel-block
- *   "overlap_chunks"     0 (default) | 2..16: channel chunks on two internal streams, the front end of
- *                            chunk k+1 beside the timing stage of chunk k (measured: no gain)
- *   "fe_waves_per_cu"    0 (default) | 1..32: cap of resident front-end waves per CU (overlap experiment)
  * and one functional switch:
  *   "afc"                0 (default, as the reference ships: radio.cpp:8) | 1 = radio_set_afc_on(): the
  *                            NCO mixer of m17_dsp.cpp:390-408,468 with the loop of radio.cpp:196-208 per channel.
@@ -242,12 +239,14 @@ int m17gpu_shard_gather_records(m17gpu_ctx *ctx, void *comm, int rank, int world
  * m17gpu_set_net_output attaches the sink of decode_stream_frame (m17_rx_parse.cpp:151-154 ->
  * m17_net_new_rx_data m17_net.cpp:53-74) to the context: while d_net != NULL every m17gpu_rx_blocks(mode 1)
  * call writes, for each record flagged M17GPU_F_DELIVERED, the 54-byte frame of m17gpu_format_net_frame into
- *   d_net [C][rec_cap][56]   at [channel][index of that record]   (rows of 56 bytes, the frame is the first 54)
- * built by the bookkeeping kernel from (stream id, m_lsf[1] AS IT STOOD AT THAT FRAME, fn, payload); rec_cap is
- * that of the m17gpu_rx_blocks call.  stream id = d_stream_ids[channel] (0 when NULL) + the channel's frame-id
+ *   d_net [C][net_rec_cap][56]   at [channel][index of that record]   (rows of 56 bytes, the frame is the first 54)
+ * built by the bookkeeping kernel from (stream id, m_lsf[1] AS IT STOOD AT THAT FRAME, fn, payload).  net_rec_cap is
+ * the sink's capacity in records per channel and must equal the rec_cap of every mode-1 m17gpu_rx_blocks call made
+ * while the sink is attached: a call with another rec_cap returns M17GPU_ERR_ARG and launches nothing (the sink is
+ * indexed with the call's rec_cap; another capacity would be written out of bounds or at the wrong rows).  stream id = d_stream_ids[channel] (0 when NULL) + the channel's frame-id
  * epoch (the event counter that stands in for the reference's rand(), m17_rx_parse.cpp:10-12), mod 2^16.
  * dst_override as in m17gpu_format_net_frame.  Rows of other records are left untouched.  d_net = NULL detaches. */
-int m17gpu_set_net_output(m17gpu_ctx *ctx, uint8_t *d_net, const uint16_t *d_stream_ids, uint64_t dst_override);
+int m17gpu_set_net_output(m17gpu_ctx *ctx, uint8_t *d_net, int net_rec_cap, const uint16_t *d_stream_ids, uint64_t dst_override);
 /* m17gpu_parse_lsf for n LSFs resident on the device: d_lsf [n][30] -> d_out [n] (64-byte structs) */
 int m17gpu_parse_lsf_batch(m17gpu_ctx *ctx, const uint8_t *d_lsf, m17gpu_lsf_fields *d_out, int n, void *stream);
 

@@ -18,6 +18,7 @@ SOFT_BITS = 368
 
 F_SYNC_OK, F_PARSED, F_LICH_OK, F_DELIVERED = 0x1, 0x2, 0x4, 0x8
 F_EOT, F_LOST, F_LSF_GATE, F_PKT_VALID, F_AOS = 0x10, 0x20, 0x40, 0x80, 0x100
+OK, ERR_NO_DEVICE, ERR_HIP, ERR_ARG, ERR_NOMEM = 0, -1, -2, -3, -4      # M17GPU_* status codes
 
 
 def sym_stride(nblk):
@@ -69,7 +70,7 @@ SIGNATURES = {
     "m17gpu_get_constant": (_i, [C.c_char_p, _vp, _i]),
     "m17gpu_format_net_frame": (_i, [C.c_uint16, _vp, C.c_uint16, _vp, _u64, _vp]),
     "m17gpu_parse_lsf": (_i, [_vp, _vp]),
-    "m17gpu_set_net_output": (_i, [_vp, _vp, _vp, _u64]),
+    "m17gpu_set_net_output": (_i, [_vp, _vp, _i, _vp, _u64]),
     "m17gpu_shard_range": (None, [_i, _i, _i, _vp, _vp]),
     "m17gpu_shard_scatter_iq": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "m17gpu_shard_gather_records": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),

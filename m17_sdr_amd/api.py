@@ -95,6 +95,9 @@ class Receiver:
         nblk = int(iq.shape[1])
         self._chk(iq, torch.int16, (self.C, nblk, 1920, 2), "iq")
         self._chk_out(out, nblk)
+        net = getattr(self, "_net", None)
+        if int(mode) == 1 and net is not None and int(net.shape[1]) != int(out["rec_cap"]):
+            raise ValueError(f"the network sink was attached with rec_cap {int(net.shape[1])}; these outputs have {int(out['rec_cap'])}")
         _check(lib().m17gpu_rx_blocks(self._ctx, _ptr(iq), nblk, int(mode), _ptr(out["recs"]),
                                       int(out["rec_cap"]), _ptr(out["counts"]), _ptr(out["syms"]),
                                       _ptr(out["nsyms"]), self._stream()), "m17gpu_rx_blocks")
@@ -217,12 +220,12 @@ class Receiver:
         if stream_ids is not None:
             self._chk(stream_ids, torch.int16, (self.C,), "stream_ids")
         self._net, self._sids = net, stream_ids                      # keep them alive while attached
-        _check(lib().m17gpu_set_net_output(self._ctx, _ptr(net), _ptr(stream_ids), int(dst_override)),
+        _check(lib().m17gpu_set_net_output(self._ctx, _ptr(net), rec_cap, _ptr(stream_ids), int(dst_override)),
                "m17gpu_set_net_output")
         return net
 
     def clear_net_output(self):
-        _check(lib().m17gpu_set_net_output(self._ctx, C.c_void_p(0), C.c_void_p(0), 0), "m17gpu_set_net_output")
+        _check(lib().m17gpu_set_net_output(self._ctx, C.c_void_p(0), 0, C.c_void_p(0), 0), "m17gpu_set_net_output")
         self._net = self._sids = None
 
     def parse_lsf_batch(self, lsf):

@@ -23,7 +23,11 @@
 #include <memory>
 #include <mutex>
 #include <dlfcn.h>
-#include <rccl/rccl.h>        // types and prototypes only: the library is resolved at first use, not linked
+// The few RCCL types the fan-out entries need, as rccl.h declares them (ABI-stable NCCL 2 values): the library is
+// resolved in the process at first use, so neither its header nor the library is a build requirement.
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclInt32 = 2 } ncclDataType_t;
 
 using namespace m17dev;
 
@@ -39,7 +43,8 @@ struct m17gpu_ctx {
     int32_t *d_work = nullptr, *d_nwork = nullptr, *d_counts = nullptr;
     uint16_t *d_genc = nullptr, *d_gerr = nullptr, *d_crc_basis = nullptr;
     uint32_t *d_dec_hist = nullptr;          // [C][32] history of the wide-band decimator
-    uint8_t *d_net = nullptr;                // optional network sink [C][rec_cap][56] (m17gpu_set_net_output); not owned
+    uint8_t *d_net = nullptr;                // optional network sink [C][net_rec_cap][56] (m17gpu_set_net_output); not owned
+    int net_rec_cap = 0;                     // its records per channel: a mode-1 call must use exactly this rec_cap
     const uint16_t *d_stream_ids = nullptr;  // optional [C] stream-id base per channel; not owned
     unsigned long long dst_override = 0;     // 48-bit destination callsign written into every net frame (0 = keep the LSF's)
     int afc = 0;                             // 1 = AFC on (radio_set_afc_on): block-sequential front end
@@ -47,12 +52,7 @@ struct m17gpu_ctx {
     int fe_impl = 0;                         // 0 = by size (four lanes per channel-block), 1 = lane per channel-block, 2 = four lanes
     int sync_impl = 0;                       // 0 | 6 = timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond (default);
                                              // 7 = wave per channel at every size
-    int fe_waves_per_cu = 0;                 // experiment: cap of front-end waves per CU (0 = none)
     int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
-    int overlap_chunks = 0;                  // > 1: channel chunks, front end of chunk k+1 beside the timing stage of chunk k (two internal streams)
-    hipStream_t aux[2] = {nullptr, nullptr}; // internal streams of the chunked mode, created on first use
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::vector<hipEvent_t> ev_chunk;        // front end of chunk k done
     std::vector<hipEvent_t> ev_pool;         // 7 events per profiled call: 5 stage marks + call start / end
     std::vector<int> ev_mode;                // mode of each profiled call
 };
@@ -169,11 +169,8 @@ int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc,
     // measured on MI355X (scripts/exp_scale.py): the 4-lane kernel wins at 51,200 .. 196,608 channel-blocks,
     // so it is the default at every size; fe_impl 1 keeps the one-lane kernel selectable
     const bool quad = ctx->fe_impl != 1;
-    // fe_waves_per_cu (experiment): unused dynamic LDS caps the front end's waves per CU so that a timing-stage launch on
-    // another stream finds register room beside it
-    const unsigned pad = ctx->fe_waves_per_cu > 0 ? (unsigned)std::max(0, 160 * 1024 / ctx->fe_waves_per_cu - 8704 - 64) : 0u;
     if (quad)
-        hipLaunchKernelGGL(k_frontend_q, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), pad, st,
+        hipLaunchKernelGGL(k_frontend_q, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state | (ctx->fe_debug << 1));
     else
         hipLaunchKernelGGL(k_frontend, dim3(cdiv(total, 64 * FE_WAVES)), dim3(64 * FE_WAVES), 0, st,
@@ -308,10 +305,6 @@ void m17gpu_destroy(m17gpu_ctx *ctx)
                     ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis, ctx->d_dec_hist};
     for (void *p : bufs) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    for (hipStream_t a : ctx->aux) if (a) (void)hipStreamDestroy(a);
     delete ctx;
 }
 
@@ -338,6 +331,10 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
     // and with them the LICH / counter / packet bookkeeping the reference does for that frame
     if (mode == 1 && (!d_recs || rec_cap < 2 * nblk + 2 || rec_cap > ctx->rec_cap_max))
         return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: mode 1 needs d_recs and 2*nblk+2 <= rec_cap <= 2*max_blocks+2");
+    // the network sink is indexed [channel][record] with the call's rec_cap: a sink of another capacity would be
+    // written out of bounds (smaller) or at the wrong rows (larger)
+    if (mode == 1 && ctx->d_net && rec_cap != ctx->net_rec_cap)
+        return fail(M17GPU_ERR_ARG, "m17gpu_rx_blocks: rec_cap differs from the capacity the network sink was attached with");
     hipStream_t st = S(stream);
     int rc;
     const bool full = mode == 1;
@@ -354,10 +351,6 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
         ev = &ctx->ev_pool[base];
     }
     if (ev) HIPCHK(hipEventRecord(ev[5], st));
-    // (Channel chunks pipelined over internal streams -- chunk c+1's front end beside chunk c's timing stage beside
-    //  chunk c-1's decoder, 2..8 chunks at 16,384 channels -- were measured and dropped: 1.10 -> 1.10..1.24 ms per
-    //  step.  Every stage is issue-bound on the same vector units (scripts/micro/valu_rates.hip), so launches that
-    //  run side by side only share them.  The launch helpers still accept a channel range.)
     {
 #define MARK(i) do { if (ev) HIPCHK(hipEventRecord(ev[i], st)); } while (0)
         MARK(0);
@@ -370,37 +363,6 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
                 if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
                                             d_syms, d_nsyms, st, -1, b, 1)) != M17GPU_OK) return rc;
             }
-            MARK(1);
-            MARK(2);
-        } else if (ctx->overlap_chunks > 1 && ctx->C >= 64 * ctx->overlap_chunks) {
-            // Channel chunks on two internal streams: the front end of chunk k+1 (HBM-bound) runs beside the timing
-            // stage of chunk k (issue/latency-bound).  Both streams fork from the caller's stream and join it again, so
-            // the call keeps stream semantics.  Stage marks 1/2 cannot be told apart here: both land at the join.
-            if (!ctx->aux[0]) {
-                for (hipStream_t &a : ctx->aux) HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-            }
-            const int nch = ctx->overlap_chunks;
-            while ((int)ctx->ev_chunk.size() < nch) {
-                hipEvent_t e;
-                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                ctx->ev_chunk.push_back(e);
-            }
-            HIPCHK(hipEventRecord(ctx->ev_fork, st));
-            HIPCHK(hipStreamWaitEvent(ctx->aux[0], ctx->ev_fork, 0));
-            HIPCHK(hipStreamWaitEvent(ctx->aux[1], ctx->ev_fork, 0));
-            const int per = ((ctx->C + nch - 1) / nch + 63) / 64 * 64;
-            for (int k = 0, c0 = 0; c0 < ctx->C; ++k, c0 += per) {
-                const int cn = std::min(per, ctx->C - c0);
-                if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, ctx->aux[0], c0, cn)) != M17GPU_OK) return rc;
-                HIPCHK(hipEventRecord(ctx->ev_chunk[k], ctx->aux[0]));
-                HIPCHK(hipStreamWaitEvent(ctx->aux[1], ctx->ev_chunk[k], 0));
-                if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
-                                            d_syms, d_nsyms, ctx->aux[1], -1, 0, -1, c0, cn)) != M17GPU_OK) return rc;
-            }
-            HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux[1]));
-            HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
             MARK(1);
             MARK(2);
         } else {
@@ -483,8 +445,6 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
 #ifdef M17_STAMPS
     else if (!std::strcmp(name, "fe_debug")) { ctx->fe_debug = value; }      // instrumented build only: WRONG results
 #endif
-    else if (!std::strcmp(name, "fe_waves_per_cu")) { if (value < 0 || value > 32) return bad(); ctx->fe_waves_per_cu = value; }
-    else if (!std::strcmp(name, "overlap_chunks")) { if (value < 0 || value > 16) return bad(); ctx->overlap_chunks = value; }
     else return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: unknown option ") + name);
     return M17GPU_OK;
 }
@@ -495,11 +455,14 @@ static_assert(sizeof(m17gpu_lsf_fields) == sizeof(LsfFieldsDev) && sizeof(m17gpu
 
 // Network sink of the full chain (SURVEY 8f-3 on the device): while set, every m17gpu_rx_blocks(mode 1) call writes the
 // 54-byte M17-over-IP frame of each DELIVERED record into d_net[channel][record index] (rows of 56 bytes).
-int m17gpu_set_net_output(m17gpu_ctx *ctx, uint8_t *d_net, const uint16_t *d_stream_ids, uint64_t dst_override)
+int m17gpu_set_net_output(m17gpu_ctx *ctx, uint8_t *d_net, int net_rec_cap, const uint16_t *d_stream_ids, uint64_t dst_override)
 {
     if (!ctx) return fail(M17GPU_ERR_ARG, "m17gpu_set_net_output: null context");
     if (dst_override >> 48) return fail(M17GPU_ERR_ARG, "m17gpu_set_net_output: dst_override is a 48-bit callsign");
-    ctx->d_net = d_net; ctx->d_stream_ids = d_net ? d_stream_ids : nullptr; ctx->dst_override = dst_override;
+    if (d_net && (net_rec_cap < 4 || net_rec_cap > ctx->rec_cap_max))
+        return fail(M17GPU_ERR_ARG, "m17gpu_set_net_output: net_rec_cap must be a mode-1 rec_cap of this context (4 .. 2*max_blocks+2)");
+    ctx->d_net = d_net; ctx->net_rec_cap = d_net ? net_rec_cap : 0;
+    ctx->d_stream_ids = d_net ? d_stream_ids : nullptr; ctx->dst_override = dst_override;
     return M17GPU_OK;
 }
 
@@ -554,6 +517,14 @@ const RcclApi &rccl()
         if (r_ != ncclSuccess)                                                                           \
             return fail(M17GPU_ERR_HIP, std::string(#expr) + ": " + (R.GetErrorString ? R.GetErrorString(r_) : "RCCL error")); \
     } while (0)
+// inside ncclGroupStart .. ncclGroupEnd: remember the first failure and keep going to the GroupEnd -- returning with the
+// group open would nest every later RCCL call of this thread inside it
+#define RCCLGRP(expr)                                                                                    \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess && grp_err.empty())                                                        \
+            grp_err = std::string(#expr) + ": " + (R.GetErrorString ? R.GetErrorString(r_) : "RCCL error"); \
+    } while (0)
 } // namespace
 extern "C" {
 
@@ -580,19 +551,21 @@ int m17gpu_shard_scatter_iq(m17gpu_ctx *ctx, void *comm, int rank, int world, in
     const size_t per = (size_t)nblk * kBlockSamples * 2 * sizeof(int16_t);       // bytes per channel
     hipStream_t st = S(stream);
     // one group: the sends to all peers are in flight together, each on its own xGMI link (a ring would be per-link bound)
+    std::string grp_err;
     RCCLCHK(R.GroupStart());
     if (rank == src_rank) {
         for (int r = 0; r < world; ++r) {
             int a, b;
             m17gpu_shard_range(r, world, n_channels_total, &a, &b);
             if (r == src_rank || b <= a) continue;
-            RCCLCHK(R.Send(reinterpret_cast<const char *>(d_iq_all) + (size_t)a * per, (size_t)(b - a) * per, ncclChar, r,
+            RCCLGRP(R.Send(reinterpret_cast<const char *>(d_iq_all) + (size_t)a * per, (size_t)(b - a) * per, ncclChar, r,
                            static_cast<ncclComm_t>(comm), st));
         }
     } else if (hi > lo) {
-        RCCLCHK(R.Recv(d_iq_mine, (size_t)(hi - lo) * per, ncclChar, src_rank, static_cast<ncclComm_t>(comm), st));
+        RCCLGRP(R.Recv(d_iq_mine, (size_t)(hi - lo) * per, ncclChar, src_rank, static_cast<ncclComm_t>(comm), st));
     }
-    RCCLCHK(R.GroupEnd());
+    RCCLGRP(R.GroupEnd());
+    if (!grp_err.empty()) return fail(M17GPU_ERR_HIP, grp_err);
     if (rank == src_rank && hi > lo)
         HIPCHK(hipMemcpyAsync(d_iq_mine, reinterpret_cast<const char *>(d_iq_all) + (size_t)lo * per, (size_t)(hi - lo) * per,
                               hipMemcpyDeviceToDevice, st));
@@ -614,21 +587,23 @@ int m17gpu_shard_gather_records(m17gpu_ctx *ctx, void *comm, int rank, int world
     ON_CTX_DEVICE(ctx);
     const size_t per = (size_t)rec_cap * sizeof(m17gpu_rec);
     hipStream_t st = S(stream);
+    std::string grp_err;
     RCCLCHK(R.GroupStart());
     if (rank == dst_rank) {
         for (int r = 0; r < world; ++r) {
             int a, b;
             m17gpu_shard_range(r, world, n_channels_total, &a, &b);
             if (r == dst_rank || b <= a) continue;
-            RCCLCHK(R.Recv(reinterpret_cast<char *>(d_recs_all) + (size_t)a * per, (size_t)(b - a) * per, ncclChar, r,
+            RCCLGRP(R.Recv(reinterpret_cast<char *>(d_recs_all) + (size_t)a * per, (size_t)(b - a) * per, ncclChar, r,
                            static_cast<ncclComm_t>(comm), st));
-            RCCLCHK(R.Recv(d_counts_all + a, (size_t)(b - a), ncclInt32, r, static_cast<ncclComm_t>(comm), st));
+            RCCLGRP(R.Recv(d_counts_all + a, (size_t)(b - a), ncclInt32, r, static_cast<ncclComm_t>(comm), st));
         }
     } else if (hi > lo) {
-        RCCLCHK(R.Send(d_recs_mine, (size_t)(hi - lo) * per, ncclChar, dst_rank, static_cast<ncclComm_t>(comm), st));
-        RCCLCHK(R.Send(d_counts_mine, (size_t)(hi - lo), ncclInt32, dst_rank, static_cast<ncclComm_t>(comm), st));
+        RCCLGRP(R.Send(d_recs_mine, (size_t)(hi - lo) * per, ncclChar, dst_rank, static_cast<ncclComm_t>(comm), st));
+        RCCLGRP(R.Send(d_counts_mine, (size_t)(hi - lo), ncclInt32, dst_rank, static_cast<ncclComm_t>(comm), st));
     }
-    RCCLCHK(R.GroupEnd());
+    RCCLGRP(R.GroupEnd());
+    if (!grp_err.empty()) return fail(M17GPU_ERR_HIP, grp_err);
     if (rank == dst_rank && hi > lo) {
         HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(d_recs_all) + (size_t)lo * per, d_recs_mine, (size_t)(hi - lo) * per,
                               hipMemcpyDeviceToDevice, st));

@@ -441,6 +441,35 @@ void m17o_decode_call(uint64_t word, char *call)
     call[9] = 0;
 }
 
+/* parse_lsf (m17_rx_parse.cpp:52-70): the fields the reference hands to valid_lsf_received / gui_save_dest_address /
+ * gui_save_src_address -- destination and source by pack_8_to_48 (m17_bit_utils.cpp:100-114, big endian), the type
+ * word by pack_8_to_16 (:125-131) through m17_upack_type (:245-254), the 14 meta bytes; the callsign texts are what
+ * the GUI makes of the addresses with m17_decode_call (:209-226).  crc / crc_ok: lsf[28..29] and the test
+ * update_lich applies before it calls parse_lsf (m17_rx_parse.cpp:79-82: CRC over all 30 bytes is 0).  The struct is
+ * zeroed first so that two parsers can be compared byte for byte. */
+void m17o_parse_lsf(const uint8_t *in, m17o_lsf_fields *out)
+{
+    memset(out, 0, sizeof *out);
+    uint64_t dst_add = 0, src_add = 0;
+    for (int i = 0; i < 6; i++) { dst_add <<= 8; dst_add |= in[i]; }
+    for (int i = 0; i < 6; i++) { src_add <<= 8; src_add |= in[6 + i]; }
+    uint16_t tw = in[12];
+    tw = (uint16_t)((tw << 8) | in[13]);
+    out->dst = dst_add;
+    out->src = src_add;
+    m17o_decode_call(dst_add, out->dst_call);
+    m17o_decode_call(src_add, out->src_call);
+    out->reserved = (tw >> 11) & 0x1F;
+    out->can = (tw >> 7) & 0xF;
+    out->est = (tw >> 5) & 0x3;
+    out->et = (tw >> 3) & 0x3;
+    out->dt = (tw >> 1) & 0x3;
+    out->p_s = tw & 0x1;
+    memcpy(out->meta, &in[14], 14);
+    out->crc = (uint16_t)((in[28] << 8) | in[29]);
+    out->crc_ok = m17o_crc(in, 30) == 0;
+}
+
 /* m17_prbs9.cpp:16-32 : x^9 + x^5 + 1, start 0x001 */
 void m17o_prbs9(uint8_t *out, int len)
 {

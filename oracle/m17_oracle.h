@@ -120,6 +120,17 @@ int      m17o_pack_1_to_8(const uint8_t *in, uint8_t *out, int len);
 void     m17o_demap_frame(const float *in, float *out);
 uint64_t m17o_encode_call(const char *call);
 void     m17o_decode_call(uint64_t w, char *call);
+/* parse_lsf (m17_rx_parse.cpp:52-70) + m17_decode_call + m17_upack_type: 64 bytes, the layout of the product's
+ * m17gpu_lsf_fields so that the two can be compared byte for byte */
+typedef struct {
+    uint64_t dst, src;
+    char     dst_call[10], src_call[10];
+    uint8_t  p_s, dt, et, est, can, reserved;
+    uint8_t  meta[14];
+    uint16_t crc;
+    uint8_t  crc_ok;
+} m17o_lsf_fields;
+void     m17o_parse_lsf(const uint8_t *lsf, m17o_lsf_fields *out);
 void     m17o_prbs9(uint8_t *out, int len);
 void     m17o_sync_check(const float *v, uint8_t *type, uint8_t *votes, float *variance);
 

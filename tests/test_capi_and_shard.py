@@ -156,6 +156,44 @@ def test_parse_lsf_fields_against_survey_kats():
     assert f.src_call == buf.value == b"AB1CD    " and f.crc_ok == 0
 
 
+def lsf_cases(n_random=300, seed=3):
+    """LSFs for the field-extraction tests: built ones (SURVEY 8c callsign KATs, broadcast, the largest base-40 word,
+    every type-word field exercised) and random bytes (CRC bad, addresses above 40**9)."""
+    import ctypes as C
+    from m17_sdr_amd import _lib
+    from tests import oracle
+    L = _lib.load()
+    rng = np.random.default_rng(seed)
+    out = []
+    adds = (0xFFFFFFFFFFFF, 0x00102C8DA29F, 0x0000009FDD51, 0, 40 ** 9 - 1, 1, 39, 40)
+    for i, dst in enumerate(adds):
+        for src in adds[1:4]:
+            b = np.zeros(30, np.uint8)
+            tw = int(rng.integers(0, 1 << 16)) if i else ((5 << 7) | (1 << 1) | 1)
+            L.m17gen_build_lsf(C.c_uint64(dst), C.c_uint64(src), tw, oracle.vp(rng.integers(0, 256, 14).astype(np.uint8)), oracle.vp(b))
+            out.append(b)
+    n_built = len(out)
+    out += [rng.integers(0, 256, 30).astype(np.uint8) for _ in range(n_random)]
+    return np.ascontiguousarray(np.stack(out)), n_built
+
+
+def test_host_lsf_parser_matches_the_oracle_restatement():
+    """m17gpu_parse_lsf (host) against m17o_parse_lsf, the oracle's restatement of parse_lsf (m17_rx_parse.cpp:52-70),
+    m17_decode_call (m17_bit_utils.cpp:209-226) and m17_upack_type (:245-254): all 64 bytes of the struct."""
+    from m17_sdr_amd import _lib
+    from tests import oracle
+    L = _lib.load()
+    lsf, n_built = lsf_cases()
+    got = np.zeros((len(lsf), 64), np.uint8)
+    want = np.full((len(lsf), 64), 0xEE, np.uint8)
+    for i in range(len(lsf)):
+        assert L.m17gpu_parse_lsf(oracle.vp(lsf[i]), oracle.vp(got[i])) == 0
+        oracle.L().m17o_parse_lsf(oracle.vp(lsf[i]), oracle.vp(want[i]))
+    np.testing.assert_array_equal(got, want)
+    assert want[:n_built, 58].all() and not want[n_built:, 58].all()       # crc_ok: built LSFs pass, random ones fail
+    assert bytes(want[0, 16:25]) == b"BROADCAST" and bytes(want[0, 26:35]) == b"G4GUO/P  "
+
+
 def test_traffic_json_comes_from_the_newest_profile_set():
     """bench.py reads roofline.traffic from profiles/traffic.json (PMC passes cannot run inside the bench process): the
     file must have been rebuilt from the newest FETCH_SIZE / WRITE_SIZE passes under profiles/, and name them."""

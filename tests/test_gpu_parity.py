@@ -162,14 +162,12 @@ def test_exact_arithmetic_selftest():
 
 
 @pytest.mark.parametrize("options", [
-    {"sync_impl": 6}, {"sync_impl": 7}, {"sync_impl": 7, "overlap_chunks": 2, "fe_waves_per_cu": 8}, {"fe_impl": 1}, {"fe_impl": 2}])
+    {"sync_impl": 6}, {"sync_impl": 7}, {"fe_impl": 1}, {"fe_impl": 2}])
 def test_every_kernel_variant_is_bit_exact(options):
     _rx_compare(C=40, nblk=22, mode=1, ebn0=200.0, nsf=12, options=options)
     _rx_compare(C=40, nblk=9, mode=1, ebn0=9.0, nsf=5, calls=3, options=options)
     _rx_compare(C=9, nblk=1, mode=0, ebn0=15.0, calls=12, options=options)
     _rx_compare(C=24, nblk=14, mode=1, ebn0=200.0, packet_mode=1, options=options)       # packet reassembly too
-    if "overlap_chunks" in options:          # the chunked path needs >= 64 channels per chunk
-        _rx_compare(C=300, nblk=7, mode=1, ebn0=9.0, nsf=5, calls=2, options=options)
 
 
 def test_awgn_sweep_curves_coincide_with_oracle():
@@ -218,9 +216,8 @@ def test_config2_1024_channels_front_end_bit_exact():
 @pytest.mark.parametrize("ebn0", [4.0, 8.0, 12.0])
 def test_config4_16384_channels_awgn_bit_exact(ebn0):
     """BASELINE configs[3] at its real size: 16,384 channels on one GPU, band-limited AWGN, signal from
-    the device generator (every channel distinct), DEFAULT options -- so the 16-lanes-per-channel
-    timing kernel (k_sync_frame_grp<16>, chosen above 4,096 channels) and the four-lane front end run
-    at the size the bench runs them.  EVERY channel's symbols, symbol counts, records and end state
+    the device generator (every channel distinct), DEFAULT options -- so the kernels the bench runs at this size
+     run here at that size.  EVERY channel's symbols, symbol counts, records and end state
     are compared with the oracle (m17_rx_sync.cpp:77-99, m17_rx_frame.cpp:126-177 and the decode chain)."""
     torch = _torch()
     import m17_sdr_amd as m
@@ -501,11 +498,11 @@ def test_set_option_rejects_unknown_and_out_of_range_values():
     import m17_sdr_amd as m
     rx = m.Receiver(2, 2)
     for name, value in (("fe_impl", 101), ("fe_impl", 107), ("fe_impl", -1), ("fe_impl", 3), ("sync_impl", 2),
-                        ("sync_impl", 5), ("sync_impl", 1), ("sync_impl", 4), ("overlap_chunks", 17), ("fe_waves_per_cu", -1), ("lanes_per_channel", 16),
+                        ("sync_impl", 5), ("sync_impl", 1), ("sync_impl", 4), ("overlap_chunks", 2), ("fe_waves_per_cu", 8), ("lanes_per_channel", 16),
                         ("decode_impl", 0), ("no_such_option", 1)):
         with pytest.raises(RuntimeError):
             rx.set_option(name, value)
-    for name, value in (("fe_impl", 0), ("fe_impl", 1), ("fe_impl", 2), ("sync_impl", 0), ("sync_impl", 6), ("sync_impl", 7), ("overlap_chunks", 4), ("fe_waves_per_cu", 8)):
+    for name, value in (("fe_impl", 0), ("fe_impl", 1), ("fe_impl", 2), ("sync_impl", 0), ("sync_impl", 6), ("sync_impl", 7)):
         rx.set_option(name, value)
     rx.close()
 
@@ -772,37 +769,42 @@ def test_net_frames_on_device_match_the_reference_sink():
             assert (int(f[34]) << 8 | int(f[35])) == recs[c, i]["fn"] and bytes(f[36:52]) == bytes(recs[c, i]["data"][8:24])
         frames += int(deliv.sum())
     assert frames > Cn * 8, frames
+    # the sink's capacity is part of the contract: a call whose rec_cap differs from it is refused before anything is
+    # launched, by the Python mirror and by the C-ABI alike (the sink is indexed with the call's rec_cap)
+    small = rx.alloc_outputs(nblk - 2)
+    assert small["rec_cap"] != net.shape[1]
+    part = torch.from_numpy(np.ascontiguousarray(sig["iq"][:, :nblk - 2])).cuda()
+    with pytest.raises(ValueError):
+        rx.rx_blocks(part, 1, small)
+    rc = m.lib().m17gpu_rx_blocks(rx._ctx, part.data_ptr(), nblk - 2, 1, small["recs"].data_ptr(), int(small["rec_cap"]),
+                                  small["counts"].data_ptr(), None, None, None)
+    assert rc == m.ERR_ARG and b"network sink" in m.lib().m17gpu_last_error()
+    assert m.lib().m17gpu_set_net_output(rx._ctx, net.data_ptr(), 2 * nblk + 3, None, 0) == m.ERR_ARG     # beyond the context's maximum
     rx.clear_net_output()
+    rx.rx_blocks(part, 1, small)                                    # detached: any valid rec_cap again
+    torch.cuda.synchronize()
     rx.close()
 
 
-def test_parse_lsf_batch_matches_host_parser():
-    """m17gpu_parse_lsf_batch (parse_lsf m17_rx_parse.cpp:52-70, m17_decode_call m17_bit_utils.cpp:209-226,
-    m17_upack_type :245-254) on the device against the host parser, struct for struct: transmitted LSFs, the
-    survey's callsign KATs, the broadcast address, random bytes (CRC bad)."""
-    import ctypes as C
+def test_parse_lsf_batch_matches_the_oracle():
+    """m17gpu_parse_lsf_batch (k_parse_lsf) on the device against m17o_parse_lsf -- the oracle's restatement of
+    parse_lsf (m17_rx_parse.cpp:52-70), m17_decode_call (m17_bit_utils.cpp:209-226) and m17_upack_type (:245-254) --
+    struct for struct: transmitted LSFs, built ones (the survey's callsign KATs, the broadcast address, every type
+    field), random bytes (CRC bad)."""
     torch = _torch()
     import m17_sdr_amd as m
-    L = m.lib()
-    rng = np.random.default_rng(3)
+    from tests.test_capi_and_shard import lsf_cases
     sig = m.generate_batch(40, 2, n_stream_frames=1)
-    lsf = [sig["lsf"][c] for c in range(40)]
-    for dst, src in ((0xFFFFFFFFFFFF, 0x00102C8DA29F), (0x0000009FDD51, 0x00102C8DA29F), (0, 40 ** 9 - 1)):
-        b = np.zeros(30, np.uint8)
-        L.m17gen_build_lsf(C.c_uint64(dst), C.c_uint64(src), (5 << 7) | (1 << 1) | 1, oracle.vp(np.arange(14, dtype=np.uint8)), oracle.vp(b))
-        lsf.append(b)
-    lsf += [rng.integers(0, 256, 30).astype(np.uint8) for _ in range(200)]
-    lsf = np.ascontiguousarray(np.stack(lsf))
+    extra, n_built = lsf_cases()
+    lsf = np.ascontiguousarray(np.concatenate([np.stack([sig["lsf"][c] for c in range(40)]), extra]))
     rx = m.Receiver(1, 1)
     got = rx.parse_lsf_batch(torch.from_numpy(lsf).cuda()).cpu().numpy()
     want = np.zeros((len(lsf), 64), np.uint8)
     for i in range(len(lsf)):
-        assert L.m17gpu_parse_lsf(oracle.vp(lsf[i]), oracle.vp(want[i])) == 0
+        oracle.L().m17o_parse_lsf(oracle.vp(lsf[i]), oracle.vp(want[i]))
     np.testing.assert_array_equal(got, want)
-    assert want[:43, 58].all() and not want[43:, 58].all()          # crc_ok of built LSFs; random ones fail
-    buf = C.create_string_buffer(10)
-    oracle.L().m17o_decode_call(C.c_uint64(0x00102C8DA29F), buf)
-    assert bytes(got[40, 26:35]) == buf.value == b"G4GUO/P  "       # src_call of the first KAT row
+    assert want[:40 + n_built, 58].all() and not want[40 + n_built:, 58].all()   # crc_ok of sent / built LSFs; random ones fail
+    assert bytes(got[40, 16:25]) == b"BROADCAST" and bytes(got[40, 26:35]) == b"G4GUO/P  "
     rx.close()
 
 
@@ -874,5 +876,7 @@ def test_squelched_channels_do_not_slow_the_timing_stage():
         torch.cuda.synchronize()
         times[name] = rx.kernel_ms()[0][1]
         rx.close()
-    assert times["zeros"] < 2.0 * times["signal"], times
-    assert times["carrier"] < 2.0 * times["signal"], times
+    # a guard against the 15x regression only (the box is shared: no tight ratio here; the measured figures are kept by
+    # scripts/exp_dead_channels.py under profiles/)
+    assert times["zeros"] < 6.0 * times["signal"], times
+    assert times["carrier"] < 6.0 * times["signal"], times
