@@ -1,0 +1,243 @@
+// m17_fused.hip -- k_rx_fused: the whole FIR stage of ONE CHANNEL IN ONE WAVE -- int16 IQ -> limiter -> FM
+// discriminator -> /5 -> DC removal (dsp_short_to_float m17_dsp.cpp:136-141, dsp_limit :412-419, dsp_arctan_disc2
+// :194-222), then the polyphase timing loop (m17_rx_sync_samples m17_rx_sync.cpp:77-99), the sync correlator and the
+// framer (m17_rx_frame.cpp:47-177) -- with the discriminator samples handed over in LDS.
+//
+// Why: as two kernels the stage wrote the discriminator stream to HBM and read it back
+// (1,536 + 1,536 B per channel-block next to 7,680 B of input: 27 % of the stage's HBM bytes), and its two halves sit
+// on different roofs -- the front end on vector-memory throughput with three quarters of its issue slots idle, the
+// timing loop on issue / dependency latency with the memory pipe idle -- which separate launches cannot overlap: the
+// front end's 124 registers x 4 waves leave no room beside it on a SIMD.  Here every wave runs BOTH phases for its
+// own channel, so at any moment some waves of a SIMD stream IQ while the others filter, and nothing but the IQ (in)
+// and the frame slots / records / symbols (out) crosses HBM.
+//
+// What makes that possible is the row mapping of the front-end phase.  The 1920-term DC sum of a block is a strictly
+// sequential fp32 chain (m17_dsp.cpp:211), affordable only with several chains side by side in the lanes of one
+// instruction; the two-kernel front end found them in 16 (channel, block) rows of OTHER channels.  A channel's own
+// blocks are just as independent of each other -- the only state the front end carries is z[0], z[1], the last two
+// limited samples, and those are in the input -- so a wave takes FU_R = 4 consecutive blocks of ITS channel as four
+// rows of 16 lanes:
+//   load    : lane (r, l) of chunk c reads the uint4 that holds samples 64c + 4l .. + 3 of row r -- 256 contiguous
+//             bytes per row per instruction; two register sets of FU_P chunks, one being computed while the other is
+//             in flight (a rotating set made the compiler copy registers and drain vmcnt at every loop latch), the
+//             first pass of the next group requested before the timing phase;
+//   compute : the lane converts, limits and discriminates its own four samples, the two before them by DPP row_shr:1
+//             (lane 0: the row's previous chunk, row_ror:1); no LDS transpose;
+//   DC sum  : the chain runs lane by lane through the row as 16 x 4 dependent adds per chunk: lane l adds its four
+//             values to lane l-1's sum (v_add_f32_dpp row_shr:1); lanes ahead of the front compute on stale input
+//             and are overwritten when the front reaches them, lane 0 adds exact zeros behind its own step;
+//   /5 pick : sample s is an output iff s % 5 == 4; with q = (c + l) % 5 the lane's pick is its sample q - 1
+//             (none for q == 0) and goes straight to its place in the row's x[] in LDS;
+//   then the row's offset is subtracted in place and the timing loop runs over the four blocks with the delay line
+//   simply continuing from one row into the next.
+// The chain costs 480 wave-instructions per channel-block here against 120 with 16 rows per wave: the price of
+// having both phases in one wave.
+#pragma clang fp contract(off)
+
+namespace m17dev {
+
+constexpr int FU_R = 4;                        // blocks per group = rows of the front-end phase
+constexpr int FU_P = 5;                        // chunks per pass: while a pass is computed, the next pass's input is in flight
+constexpr int FU_NCHUNK = kBlockSamples / 64;  // 30 chunks of 64 samples per row
+constexpr int FU_WAVES = 4;                    // channels (waves) per workgroup; the waves never synchronise
+// x[] of one channel: [2 pad][30 delay line][FU_R x 384 block inputs][124 read past the last block, never used]
+constexpr int FU_XF = 2 + (kTaps - 1) + FU_R * kDiscOut + 124 + 4;
+static_assert(FU_XF % 4 == 0 && FU_NCHUNK % (2 * FU_P) == 0, "fused kernel layout");
+
+template <int CTRL> __device__ __forceinline__ float dpp_keep(float old, float src)    // lanes without a source keep `old`
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xF, 0xF, false));
+}
+// value of lane l-1 of the row; lane 0: lane 15's value of `prev` (the row's previous chunk)
+__device__ __forceinline__ float fu_left(float cur, float prev)
+{
+    const float t = dpp_keep<0x121>(prev, prev);          // row_ror:1
+    return dpp_keep<0x111>(t, cur);                       // row_shr:1
+}
+
+// The DC sum of one chunk (m17_dsp.cpp:211: offset += out, strictly in sample order): on entry `carry` holds, in lane
+// 0 of each row, the row's sum so far; u0..u3 the lane's four values, a0..a3 the same with exact zeros in lane 0.
+// Lane 0 finishes in the first four adds; after step j lanes 0..j hold their final sums (lane l <= j recomputes the
+// same value from lane l-1's final one; lane 0 is disabled for the DPP add -- no source, bound_ctrl 0 -- and adds
+// zeros, which is exact: a running sum that starts at +0 never is -0).  Leaves the row's new sum in lane 0 of `carry`.
+// (s_nop 1: a VALU write followed by a DPP read of the same register needs two wait states on gfx9.)
+#define FU_STEP "s_nop 1\n\tv_add_f32_dpp %0, %0, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+                "v_add_f32 %0, %0, %7\n\tv_add_f32 %0, %0, %8\n\tv_add_f32 %0, %0, %9\n\t"
+__device__ __forceinline__ void fu_chain(float &carry, float u0, float u1, float u2, float u3, float a0, float a1, float a2, float a3)
+{
+    float T;
+    asm volatile("v_add_f32 %0, %1, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %0, %0, %4\n\tv_add_f32 %0, %0, %5\n\t"
+                 FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP
+                 "s_nop 1\n\tv_mov_b32_dpp %1, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(T), "+v"(carry) : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+}
+
+__global__ __launch_bounds__(64 * FU_WAVES, 4)
+void k_rx_fused(const uint4 *__restrict__ iq,              // [C][nblk][480] uint4 (4 IQ samples each)
+                ChanState *__restrict__ st, int C, int nblk, int mode,
+                m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
+                float *__restrict__ syms, int32_t *__restrict__ nsyms, float *__restrict__ fsym)
+{
+    constexpr int LPC = 64;
+    __shared__ __attribute__((aligned(2048))) float rings[FU_WAVES][kWvRing];
+    __shared__ __attribute__((aligned(16))) float xs[FU_WAVES][FU_XF];
+    const int wave = uni((int)(threadIdx.x >> 6)), gl = lane_id();
+    const int chan = (int)blockIdx.x * FU_WAVES + wave;
+    if (chan >= C) return;
+    const unsigned hb = (unsigned)uni((int)(unsigned)(uintptr_t)(lds_cfp)rings[wave]);
+    float *const X = &xs[wave][2];                                    // x[0..29] delay line, x[30 + 384 r + i] row r
+    const unsigned xb = (unsigned)uni((int)(unsigned)(uintptr_t)(lds_cfp)X);
+    ChanState &cs = st[chan];
+    if (!recs) rec_cap = 0;
+
+    WvCtl t;
+    wv_load_state(t, cs, counts, chan, 0, hb, gl);
+    RegroupLane<LPC> rg;
+    rg.load(gl);
+    WvOut o;
+    o.crecs = recs ? recs + (size_t)chan * rec_cap : nullptr; o.rec_cap = rec_cap;
+    o.sym_out = syms ? syms + (size_t)chan * M17_SYM_STRIDE(nblk) : nullptr;
+    o.nsyms_row = nsyms ? nsyms + (size_t)chan * nblk : nullptr;
+    o.fsym_chan = fsym + (size_t)chan * rec_cap * kSlotFloats;
+    o.mode = mode; o.ext_lock = -1;
+    if (gl < kTaps - 1) X[gl] = cs.buff[gl + 1];
+    unsigned *wst = nullptr;
+#ifdef M17_STAMPS
+    __shared__ unsigned wstamps[FU_WAVES][12];
+    if (gl < 12) wstamps[wave][gl] = 0;
+    wst = wstamps[wave];
+    t.last_ = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- front-end phase set-up: lane (r, l)
+    const int r = gl >> 4, l = gl & 15;
+    const uint4 *const iqc = iq + (size_t)chan * nblk * (kBlockSamples / 4);
+    // z[0], z[1] for the NEXT call: the limited last two samples of the channel's last block (m17_dsp.cpp:196,205-206)
+    float n0re, n0im, n1re, n1im;
+    fe_next_z(iq, chan * nblk, nblk, n0re, n0im, n1re, n1im);
+    const float s0re = cs.z0re, s0im = cs.z0im, s1re = cs.z1re, s1im = cs.z1im;
+
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    const int ngroups = (nblk + FU_R - 1) / FU_R;
+    // the lane's uint4 of chunk cc (counted through the whole call: group cc / 30, chunk cc % 30); rows beyond the call
+    // read the group's first row instead (their results are never used)
+    auto load_chunk = [&](int cc) {
+        const int g = cc / FU_NCHUNK, c = cc - g * FU_NCHUNK;
+        int blk = g * FU_R + r;
+        blk = blk < nblk ? blk : g * FU_R;
+        return __builtin_nontemporal_load(reinterpret_cast<const u4v *>(iqc + (size_t)blk * (kBlockSamples / 4) + c * 16 + l));
+    };
+    const int total_chunks = ngroups * FU_NCHUNK;
+    u4v wa[FU_P], wb[FU_P];
+#pragma unroll
+    for (int j = 0; j < FU_P; ++j) wa[j] = load_chunk(j);         // total_chunks >= 30 > FU_P
+
+    for (int g = 0; g < ngroups; ++g) {
+        WSTAMP(5);
+        const int blk = g * FU_R + r;
+        const bool valid = blk < nblk;
+        // the two limited samples in front of the row: channel state for the call's first block, else the input itself
+        float p3re, p3im, p2re, p2im;                       // "previous chunk" values: sample -1 (z0) and -2 (z1), in every lane
+        if (blk == 0 || !valid) { p3re = s0re; p3im = s0im; p2re = s1re; p2im = s1im; }
+        else {
+            const uint32_t *pw = reinterpret_cast<const uint32_t *>(iqc) + (size_t)blk * kBlockSamples;
+            const uint32_t a = pw[-2], b = pw[-1];
+            p2re = s16_to_float((int)(short)(a & 0xFFFF)); p2im = s16_to_float((int)a >> 16);
+            p3re = s16_to_float((int)(short)(b & 0xFFFF)); p3im = s16_to_float((int)b >> 16);
+            limit(p2re, p2im);
+            limit(p3re, p3im);
+        }
+        float carry = 0.0f;                                  // offset = 0 (m17_dsp.cpp:199)
+        int q = l % 5;                                       // (c + l) % 5
+        const unsigned rowb = xb + 4u * (unsigned)((kTaps - 1) + kDiscOut * r);       // LDS byte address of the row's x[30]
+        const bool first = l == 0;
+        // one chunk: the lane's four samples v of chunk c
+        auto chunk = [&](const u4v v, const int c) {
+            const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+            float re[4], im[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                re[k] = s16_to_float((int)(short)(ww[k] & 0xFFFF));
+                im[k] = s16_to_float((int)ww[k] >> 16);
+                limit(re[k], im[k]);
+            }
+            const float m1re = fu_left(re[3], p3re), m1im = fu_left(im[3], p3im);     // sample -1 of this lane's run
+            const float m2re = fu_left(re[2], p2re), m2im = fu_left(im[2], p2im);     // sample -2
+            p3re = re[3]; p3im = im[3]; p2re = re[2]; p2im = im[2];
+            float u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // dsp_arctan_disc2 (m17_dsp.cpp:194-222): z0 = sample k-1, z1 = sample k-2
+                const float z0re = k >= 1 ? re[k >= 1 ? k - 1 : 0] : m1re, z0im = k >= 1 ? im[k >= 1 ? k - 1 : 0] : m1im;
+                const float z1re = k >= 2 ? re[k >= 2 ? k - 2 : 0] : (k == 1 ? m1re : m2re);
+                const float z1im = k >= 2 ? im[k >= 2 ? k - 2 : 0] : (k == 1 ? m1im : m2im);
+                const float aa = z0im * (re[k] - z1re);
+                const float bb = z0re * (im[k] - z1im);
+                u[k] = (bb - aa) * 0.5f;
+            }
+            fu_chain(carry, u[0], u[1], u[2], u[3], first ? 0.0f : u[0], first ? 0.0f : u[1], first ? 0.0f : u[2], first ? 0.0f : u[3]);
+            // count % 5 == 0 pick (m17_dsp.cpp:207-210; 1920 % 5 == 0 keeps the phase from block to block)
+            const float pick = q == 1 ? u[0] : (q == 2 ? u[1] : (q == 3 ? u[2] : u[3]));
+            const unsigned oidx = ((unsigned)(64 * c + 4 * l + q - 5) * 52429u) >> 18;        // (s - 4) / 5, s = 64c + 4l + q - 1
+            if (q != 0 && valid) *(lds_f *)(uintptr_t)(rowb + 4u * oidx) = pick;
+            q = (q == 4) ? 0 : q + 1;
+        };
+        for (int c0 = 0; c0 < FU_NCHUNK; c0 += 2 * FU_P) {
+            // pass A: chunks c0 .. c0 + P - 1 from wa, pass B's input requested first
+#pragma unroll
+            for (int j = 0; j < FU_P; ++j) wb[j] = load_chunk(g * FU_NCHUNK + c0 + FU_P + j);
+#pragma unroll
+            for (int j = 0; j < FU_P; ++j) chunk(wa[j], c0 + j);
+            // pass B: chunks c0 + P .. c0 + 2P - 1 from wb; the next pass A (of the next group behind the last one: it
+            // stays in flight through the timing phase)
+            {
+                const int cc = g * FU_NCHUNK + c0 + 2 * FU_P;
+                if (cc < total_chunks) {
+#pragma unroll
+                    for (int j = 0; j < FU_P; ++j) wa[j] = load_chunk(cc + j);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FU_P; ++j) chunk(wb[j], c0 + FU_P + j);
+        }
+        // offset / len, out[i] -= offset (m17_dsp.cpp:213,217-219): the row's sum sits in lane 0 of `carry`
+        const float off = __int_as_float(__builtin_amdgcn_ds_bpermute((gl & 48) << 2, __float_as_int(carry))) / (float)kBlockSamples;
+        wave_fence();
+        {
+            float4 *row4 = reinterpret_cast<float4 *>(X + (kTaps - 1) + kDiscOut * r);
+#pragma unroll
+            for (int j = 0; j < kDiscOut / 64; ++j) {
+                float4 d = row4[j * 16 + l];
+                d.x = d.x - off; d.y = d.y - off; d.z = d.z - off; d.w = d.w - off;
+                if (valid) row4[j * 16 + l] = d;
+            }
+        }
+        wave_fence();
+        WSTAMP(6);
+
+        // ---- timing loop + framer over the group's blocks; row rr's delay line is the tail of row rr - 1
+        const int nrows = min(FU_R, nblk - g * FU_R);
+        for (int rr = 0; rr < nrows; ++rr) {
+            const int n = wv_timing_block(t, xb + 4u * (unsigned)(kDiscOut * rr), hb, gl, t.flock, wst);
+            wave_fence();
+            wv_framer_block(t, o, n, g * FU_R + rr, hb, gl, rg, wst);
+            wave_fence();
+        }
+        // delay line of the next group: the last 30 inputs
+        {
+            const float keep_x = (gl < kTaps - 1) ? X[kDiscOut * nrows + gl] : 0.0f;
+            wave_fence();
+            if (gl < kTaps - 1) X[gl] = keep_x;
+            wave_fence();
+        }
+    }
+#ifdef M17_STAMPS
+    WSTAMP(5);
+    if (chan < 4096 && gl < 8) g_chan_stamps[chan][gl] = wstamps[wave][gl < 7 ? gl : 8];
+#endif
+    wv_store_state(t, cs, counts, chan, -1, hb, gl);
+    if (gl < kTaps - 1) cs.buff[gl + 1] = X[gl];
+    if (gl == 0) { cs.z0re = n0re; cs.z0im = n0im; cs.z1re = n1re; cs.z1im = n1im; }
+}
+
+} // namespace m17dev

@@ -103,6 +103,224 @@ __device__ __forceinline__ void store_frame_slot_wave(float *__restrict__ fd, in
 
 constexpr int WV_WAVES = 4;                    // channels (waves) per workgroup; the waves never synchronise
 
+#ifdef M17_STAMPS
+#define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0); if (gl == 0) wst[i] += now_ - t.last_; t.last_ = now_; } while (0)
+#define WCNT(i) do { if (gl == 0) wst[i] += 1; } while (0)
+#else
+#define WSTAMP(i) do {} while (0)
+#define WCNT(i) do {} while (0)
+#endif
+
+// Wave-uniform control state of one channel: the reference's file statics of the timing loop (m17_rx_sync.cpp:6-9,78)
+// and of the framer (m17_rx_frame.cpp:16-18) plus this call's counters.  Scalar registers in both kernels that use it.
+struct WvCtl {
+    int clk, thr, index;                       // m_clk, m_thr, m_index
+    float cs_, cd_;                            // carried (sum, dif): lane `clane` of these
+    int clane;
+    int flock, fclk, ferr;                     // m_flock, m_fclk, m_frame_errors
+    uint32_t block_count;
+    int nrec, sym_total;
+    int hp;                                    // ring position of the block's first symbol
+#ifdef M17_STAMPS
+    unsigned last_;
+#endif
+};
+
+// m17_rx_sync_samples (m17_rx_sync.cpp:77-99) over ONE block of 384 inputs: x[i .. i+30] is the delay line at input i,
+// xb the LDS byte address of x[0] (8-byte aligned; up to 124 floats behind x[413] are read and never used), hb that of
+// the channel's symbol ring.  Rounds of 64 instants; symbols go into the ring from t.hp on.  Returns the symbol count.
+__device__ __forceinline__ int wv_timing_block(WvCtl &t, const unsigned xb, const unsigned hb, const int gl, const int lockv, unsigned *wst)
+{
+    constexpr int LPC = 64;
+    const int thresh = lockv ? 80 : 10;
+    int p = 0, m_idx = 0;
+    // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72): the first input of a block whose
+    // predecessor ended on a filter instant, and the input behind a wrap of the branch
+    auto tick = [&]() {
+        t.clk = 0;
+        const float sum = readlane_f(t.cs_, t.clane), dif = readlane_f(t.cd_, t.clane);
+        const float d0 = (sum < 0.0f) ? -dif : dif;
+        if (d0 > 0.0f) t.thr++;
+        if (d0 < 0.0f) t.thr--;
+        if (t.thr > thresh) {
+            t.index = (t.index + 1 == kPhases) ? 0 : t.index + 1; t.thr = 0;
+            if (t.index == 0) { t.clk = 1; if (m_idx >= 0 && gl == 0) ring_st(t.hp + m_idx, hb, 0.0f); m_idx++; }
+        }
+        if (t.thr < -thresh) {
+            t.thr = 0; t.index = (t.index == 0) ? kPhases - 1 : t.index - 1;
+            if (t.index == kPhases - 1) { t.clk = 1; m_idx--; }
+        }
+        p++;
+    };
+    while (t.clk == 1 && p < kDiscOut) tick();
+    while (p < kDiscOut) {
+        WCNT(8);
+        WSTAMP(0);
+        // Lane g takes the instant at input p + 2g.  Near the end of the block the upper lanes run past it: their
+        // windows read what follows the block in the channel's LDS, and nothing of theirs is used -- no vote (okm),
+        // no symbol (naccept <= nv), no carried value.
+        const v2f a = fir_window_s(&c_tab.tap_pairs[t.index][0], ((unsigned)gl << 3) + (xb + ((unsigned)(p & ~1) << 2)), (p & 1) != 0);
+        WSTAMP(1);
+        const float s = a.x, d = a.y;
+        const int rem = kDiscOut - p;                     // >= 1
+        const int nv = min(LPC, (rem + 1) >> 1);          // filter instants of this round
+        const int nvote = min(LPC, rem >> 1);             // ... whose vote tick p + 2g + 1 is inside the block
+        const unsigned long long okm = (nvote >= 64) ? ~0ull : ((1ull << nvote) - 1ull);
+        const float dd = (s < 0.0f) ? -d : d;             // sync_update, m17_rx_sync.cpp:38-42
+        const unsigned long long um = __builtin_amdgcn_ballot_w64(dd > 0.0f) & okm;
+        const unsigned long long dm = __builtin_amdgcn_ballot_w64(dd < 0.0f) & okm;
+        const int nu = (int)__popcll(um), nd = (int)__popcll(dm);
+        int naccept = nv, kl = -1, ts_ = 0;
+        if (t.thr + nu > thresh || t.thr - nd < -thresh) {
+            // a crossing is possible in this round: the counter after every tick, first crossing wins
+            const int pu = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+            const int pd = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0u));
+            const int own = (int)((um >> gl) & 1ull) - (int)((dm >> gl) & 1ull);
+            const int tk = t.thr + pu - pd + own;
+            const unsigned long long cr = __builtin_amdgcn_ballot_w64(tk > thresh || tk < -thresh) & okm;
+            if (cr) {
+                kl = (int)__builtin_ctzll(cr);
+                naccept = kl + 1;
+                ts_ = __builtin_amdgcn_readlane(tk, kl);
+            }
+        }
+        if (gl < naccept && (m_idx + gl) >= 0) ring_st(t.hp + m_idx + gl, hb, s);
+        m_idx += naccept;
+        t.cs_ = s; t.cd_ = d; t.clane = naccept - 1;       // the carried sum/dif stay in their lane until a tick needs them
+        if (kl >= 0) {
+            t.thr = 0; t.clk = 0;
+            if (ts_ > thresh) {
+                t.index = (t.index + 1 == kPhases) ? 0 : t.index + 1;
+                if (t.index == 0) { t.clk = 1; if (m_idx >= 0 && gl == 0) ring_st(t.hp + m_idx, hb, 0.0f); m_idx++; }
+            } else {
+                t.index = (t.index == 0) ? kPhases - 1 : t.index - 1;
+                if (t.index == kPhases - 1) { t.clk = 1; m_idx--; }
+            }
+            p = p + 2 * kl + 2;
+            while (t.clk == 1 && p < kDiscOut) tick();     // a wrap: the next input is a vote tick again
+        } else {
+            t.thr += nu - nd;
+            p += 2 * nv;                                   // behind the last instant's vote tick ...
+            t.clk = p > kDiscOut ? 1 : 0;                  // ... which falls into the next block when that instant is input 383
+            p = min(p, kDiscOut);
+        }
+        WSTAMP(2);
+    }
+    return m_idx > 0 ? m_idx : 0;
+}
+
+// The block's n symbols, in the ring from t.hp on: optional symbol stream out, then the framer (m17_rx_sym,
+// m17_rx_frame.cpp:126-177) -- records, frame slots for the decoder -- and the ring position of the next block.
+struct WvOut {
+    m17gpu_rec_dev *crecs; int rec_cap;
+    float *sym_out; int32_t *nsyms_row;        // this channel's symbol stream (advances) / per-block counts, or null
+    float *fsym_chan;                          // this channel's frame slots [rec_cap][kSlotFloats]
+    int mode, ext_lock;
+};
+__device__ __forceinline__ void wv_framer_block(WvCtl &t, WvOut &o, const int n, const int b, const unsigned hb, const int gl,
+                                                const RegroupLane<64> &rg, unsigned *wst)
+{
+    constexpr int LPC = 64;
+    if (o.sym_out) {
+#pragma unroll
+        for (int r = 0; r < (193 + LPC - 1) / LPC; ++r) {
+            const int q = gl + LPC * r;
+            if (q < n) __builtin_nontemporal_store(ring_ld(t.hp + q, hb), &o.sym_out[q]);
+        }
+        o.sym_out += n;
+    }
+    if (o.nsyms_row && gl == 0) o.nsyms_row[b] = n;
+    t.sym_total += n;
+
+    WSTAMP(3);
+    int pos = (o.ext_lock >= 0) ? n : 0;
+    while (pos < n) {
+        WCNT(10);
+        if (t.flock) {
+            const int cnt = min(kFrameSyms - t.fclk, n - pos);
+            t.fclk += cnt; pos += cnt;
+            if (t.fclk == kFrameSyms) {
+                t.fclk = 0;
+                const int fs = t.hp + pos - kFrameSyms;               // the frame sits in the ring, in place
+                const SyncResult r = sync_check_lanes8(ring_ld(fs + (gl & 7), hb), sync_sign_mask(gl));
+                uint32_t flags = 0;
+                bool parse = false, unlock = false;
+                if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
+                else if (sync_accept(r, true)) { flags |= M17_F_SYNC_OK; parse = true; t.ferr = 0; }
+                else {
+                    t.ferr++;
+                    if (t.ferr > 5) { flags |= M17_F_LOST; unlock = true; }
+                    else parse = true;
+                }
+                if (parse && o.mode == 1) flags |= M17_F_PARSED;
+                const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(t.ferr & 0xFF) << 24);
+                emit_record_wave(o.crecs, o.rec_cap, t.nrec, gl, w0, flags, r.variance, t.block_count, (uint32_t)(pos - 1));
+                if ((flags & M17_F_PARSED) && t.nrec < o.rec_cap && r.type >= 1 && r.type <= 3) {
+                    float *fd = o.fsym_chan + (size_t)t.nrec * kSlotFloats;
+                    store_frame_slot_wave(fd, r.type, gl, rg.w, fs, hb);
+                }
+                t.nrec++;
+                if (unlock) {
+                    t.flock = 0;
+                    // reset_sync(): the next hunt windows must see zeros behind them
+                    wave_fence();
+                    if (gl < 8) ring_st(t.hp + pos - 8 + gl, hb, 0.0f);
+                    wave_fence();
+                }
+            }
+        } else {
+            // hunt: candidate symbol j = pos + lane, window = ring [hp + j - 7, hp + j]
+            SyncResult r;
+            const int l = hunt_pass(pos, n, gl, [&](int i) { return ring_ld(t.hp + i, hb); }, r);
+            if (l >= 0) {
+                const int js = pos + l;
+                // copy_sync(); m_fclk = 8; lock; m17_aos(): the window already is the head of the frame
+                t.fclk = 8; t.ferr = 0; t.flock = 1;
+                emit_record_wave(o.crecs, o.rec_cap, t.nrec, gl, (uint32_t)r.type | ((uint32_t)r.votes << 8), M17_F_AOS, r.variance,
+                                 t.block_count, (uint32_t)js);
+                t.nrec++;
+                pos = js + 1;
+            } else {
+                pos = min(n, pos + LPC);
+            }
+        }
+    }
+    t.hp = (t.hp + n) & (kWvRing - 1);
+    if (o.ext_lock < 0) t.block_count++;
+    WSTAMP(4);
+}
+
+// channel state <-> control registers / ring (ChanState keeps the reference's layout: m_f_sym[0 .. fclk) is the frame
+// in progress = ring [hp - fclk, hp); m_sync the last 8 symbols)
+__device__ __forceinline__ void wv_load_state(WvCtl &t, const ChanState &cs, const int32_t *counts, int chan, int b0, unsigned hb, int gl)
+{
+    t.clk = uni(cs.clk); t.thr = uni(cs.thr); t.index = uni(cs.index);
+    t.cs_ = cs.sum; t.cd_ = cs.dif; t.clane = 0;
+    t.flock = uni(cs.flock); t.fclk = uni(cs.fclk); t.ferr = uni(cs.ferr);
+    t.block_count = (uint32_t)uni((int)cs.block_count);
+    t.nrec = (b0 == 0) ? 0 : uni(counts[chan]);
+    t.sym_total = (b0 == 0) ? 0 : uni(cs.sym_total);
+    t.hp = 256;
+    if (t.flock) { for (int q = gl; q < t.fclk; q += 64) ring_st(t.hp - t.fclk + q, hb, cs.fsym[q]); }
+    else if (gl < 8) ring_st(t.hp - 8 + gl, hb, cs.sync[gl]);
+}
+__device__ __forceinline__ void wv_store_state(const WvCtl &t, ChanState &cs, int32_t *counts, int chan, int ext_lock, unsigned hb, int gl)
+{
+    const float sum_out = readlane_f(t.cs_, t.clane), dif_out = readlane_f(t.cd_, t.clane);
+    if (gl == 0) {
+        cs.clk = t.clk; cs.thr = t.thr; cs.index = t.index; cs.sum = sum_out; cs.dif = dif_out; cs.buff[0] = 0.0f;
+        if (ext_lock < 0) {
+            cs.flock = t.flock; cs.fclk = t.fclk; cs.ferr = t.ferr; cs.block_count = t.block_count; cs.sym_total = t.sym_total;
+            if (counts) counts[chan] = t.nrec;
+        }
+    }
+    if (ext_lock < 0) {
+        if (t.flock) { for (int q = gl; q < kFrameSyms; q += 64) cs.fsym[q] = ring_ld(t.hp - t.fclk + q, hb); }
+        else if (gl < 8) cs.sync[gl] = ring_ld(t.hp - 8 + gl, hb);
+    }
+}
+
 __global__ __launch_bounds__(64 * WV_WAVES, 6)
 void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                        const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
@@ -112,7 +330,6 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                        float *__restrict__ fsym, int b0, int bcount)
 {
     constexpr int LPC = 64;
-    constexpr int RM = kWvRing - 1;
     __shared__ __attribute__((aligned(4096))) WvChan chs[WV_WAVES];
     const int wave = uni((int)(threadIdx.x >> 6)), gl = lane_id();
     const int chan = (int)blockIdx.x * WV_WAVES + wave;
@@ -120,25 +337,20 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
     WvChan &my = chs[wave];
     const unsigned hb = (unsigned)uni((int)(unsigned)(uintptr_t)(lds_cfp)my.H);       // LDS byte address of the ring
     ChanState &cs = st[chan];
-    m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
     if (!recs) rec_cap = 0;
 
-    // wave-uniform control state: scalar registers
-    int clk = uni(cs.clk), thr = uni(cs.thr), index = uni(cs.index);
-    float cs_ = cs.sum, cd_ = cs.dif;                        // carried (sum, dif): lane `clane` of these
-    int clane = 0;
-    int flock = uni(cs.flock), fclk = uni(cs.fclk), ferr = uni(cs.ferr);
-    uint32_t block_count = (uint32_t)uni((int)cs.block_count);
-    int nrec = (b0 == 0) ? 0 : uni(counts[chan]);
-    int sym_total = (b0 == 0) ? 0 : uni(cs.sym_total);
-    int hp = 256;                                           // ring position of the block's first symbol
+    WvCtl t;
+    wv_load_state(t, cs, counts, chan, b0, hb, gl);
     RegroupLane<LPC> rg;
     rg.load(gl);
+    WvOut o;
+    o.crecs = recs ? recs + (size_t)chan * rec_cap : nullptr; o.rec_cap = rec_cap;
+    o.sym_out = syms ? syms + (size_t)chan * M17_SYM_STRIDE(nblk) + t.sym_total : nullptr;
+    o.nsyms_row = nsyms ? nsyms + (size_t)chan * nblk : nullptr;
+    o.fsym_chan = fsym + (size_t)chan * rec_cap * kSlotFloats;
+    o.mode = mode; o.ext_lock = ext_lock;
 
     if (gl < kTaps - 1) my.x[gl] = cs.buff[gl + 1];
-    // m_f_sym[0 .. fclk) is the frame in progress: ring [hp - fclk, hp); m_sync is the last 8 symbols
-    if (flock) { for (int q = gl; q < fclk; q += LPC) my.H[(hp - fclk + q) & RM] = cs.fsym[q]; }
-    else if (gl < 8) my.H[(hp - 8 + gl) & RM] = cs.sync[gl];
     const float *dsrc = disc + (size_t)chan * nblk * kDiscOut;
     const float *osrc = offs ? offs + (size_t)chan * nblk : nullptr;
     {
@@ -150,102 +362,22 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
             my.x[kTaps - 1 + gl + LPC * r] = v;
         }
     }
-    float *sym_out = syms ? syms + (size_t)chan * M17_SYM_STRIDE(nblk) + sym_total : nullptr;
     wave_fence();
 
     const unsigned xb = (unsigned)uni((int)(unsigned)(uintptr_t)(lds_cfp)my.x);       // LDS byte address of x[]
     const int bend = b0 + bcount;
+    unsigned *wst = nullptr;
 #ifdef M17_STAMPS
     // phase accumulators in LDS (the scalar registers are spoken for): lane 0 adds the ticks since the last stamp
     __shared__ unsigned wstamps[WV_WAVES][12];
     if (gl < 12) wstamps[wave][gl] = 0;
-    unsigned last_ = (unsigned)__builtin_amdgcn_s_memtime();
-#define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); \
-    __builtin_amdgcn_sched_barrier(0); if (gl == 0) wstamps[wave][i] += now_ - last_; last_ = now_; } while (0)
-#define WCNT(i) do { if (gl == 0) wstamps[wave][i] += 1; } while (0)
-#else
-#define WSTAMP(i) do {} while (0)
-#define WCNT(i) do {} while (0)
+    wst = wstamps[wave];
+    t.last_ = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
     for (int b = b0; b < bend; ++b) {
         WSTAMP(5);
-        // ---- timing recovery in rounds of 64 instants; x[i .. i+30] is the delay line at input i
-        const int lockv = (ext_lock >= 0) ? ext_lock : flock;        // m17_rx_lock(): the framer's state after the previous block
-        const int thresh = lockv ? 80 : 10;
-        int p = 0, m_idx = 0;
-        // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72): the first input of a block whose
-        // predecessor ended on a filter instant, and the input behind a wrap of the branch
-        auto tick = [&]() {
-            clk = 0;
-            const float sum = readlane_f(cs_, clane), dif = readlane_f(cd_, clane);
-            const float d0 = (sum < 0.0f) ? -dif : dif;
-            if (d0 > 0.0f) thr++;
-            if (d0 < 0.0f) thr--;
-            if (thr > thresh) {
-                index = (index + 1 == kPhases) ? 0 : index + 1; thr = 0;
-                if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.H[(hp + m_idx) & RM] = 0.0f; m_idx++; }
-            }
-            if (thr < -thresh) {
-                thr = 0; index = (index == 0) ? kPhases - 1 : index - 1;
-                if (index == kPhases - 1) { clk = 1; m_idx--; }
-            }
-            p++;
-        };
-        while (clk == 1 && p < kDiscOut) tick();
-        while (p < kDiscOut) {
-            WCNT(8);
-            WSTAMP(0);
-            // Lane g takes the instant at input p + 2g.  Near the end of the block the upper lanes run past it: their
-            // windows read what follows x[] in the channel's LDS (padding and the head of the ring), and nothing of
-            // theirs is used -- no vote (okm), no symbol (naccept <= nv), no carried value.
-            const v2f a = fir_window_s(&c_tab.tap_pairs[index][0], ((unsigned)gl << 3) + (xb + ((unsigned)(p & ~1) << 2)), (p & 1) != 0);
-            WSTAMP(1);
-            const float s = a.x, d = a.y;
-            const int rem = kDiscOut - p;                     // >= 1
-            const int nv = min(LPC, (rem + 1) >> 1);          // filter instants of this round
-            const int nvote = min(LPC, rem >> 1);             // ... whose vote tick p + 2g + 1 is inside the block
-            const unsigned long long okm = (nvote >= 64) ? ~0ull : ((1ull << nvote) - 1ull);
-            const float dd = (s < 0.0f) ? -d : d;             // sync_update, m17_rx_sync.cpp:38-42
-            const unsigned long long um = __builtin_amdgcn_ballot_w64(dd > 0.0f) & okm;
-            const unsigned long long dm = __builtin_amdgcn_ballot_w64(dd < 0.0f) & okm;
-            const int nu = (int)__popcll(um), nd = (int)__popcll(dm);
-            int naccept = nv, kl = -1, ts_ = 0;
-            if (thr + nu > thresh || thr - nd < -thresh) {
-                // a crossing is possible in this round: the counter after every tick, first crossing wins
-                const int pu = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
-                const int pd = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0u));
-                const int own = (int)((um >> gl) & 1ull) - (int)((dm >> gl) & 1ull);
-                const int tk = thr + pu - pd + own;
-                const unsigned long long cr = __builtin_amdgcn_ballot_w64(tk > thresh || tk < -thresh) & okm;
-                if (cr) {
-                    kl = (int)__builtin_ctzll(cr);
-                    naccept = kl + 1;
-                    ts_ = __builtin_amdgcn_readlane(tk, kl);
-                }
-            }
-            if (gl < naccept && (m_idx + gl) >= 0) ring_st(hp + m_idx + gl, hb, s);
-            m_idx += naccept;
-            cs_ = s; cd_ = d; clane = naccept - 1;            // the carried sum/dif stay in their lane until a tick needs them
-            if (kl >= 0) {
-                thr = 0; clk = 0;
-                if (ts_ > thresh) {
-                    index = (index + 1 == kPhases) ? 0 : index + 1;
-                    if (index == 0) { clk = 1; if (m_idx >= 0 && gl == 0) my.H[(hp + m_idx) & RM] = 0.0f; m_idx++; }
-                } else {
-                    index = (index == 0) ? kPhases - 1 : index - 1;
-                    if (index == kPhases - 1) { clk = 1; m_idx--; }
-                }
-                p = p + 2 * kl + 2;
-                while (clk == 1 && p < kDiscOut) tick();       // a wrap: the next input is a vote tick again
-            } else {
-                thr += nu - nd;
-                p += 2 * nv;                                   // behind the last instant's vote tick ...
-                clk = p > kDiscOut ? 1 : 0;                    // ... which falls into the next block when that instant is input 383
-                p = min(p, kDiscOut);
-            }
-            WSTAMP(2);
-        }
-        const int n = m_idx > 0 ? m_idx : 0;
+        // m17_rx_lock(): the framer's state after the previous block
+        const int n = wv_timing_block(t, xb, hb, gl, (ext_lock >= 0) ? ext_lock : t.flock, wst);
         wave_fence();
         // next block's input: requested here, behind the filter rounds (whose 40-odd window registers leave no room
         // for six more), and moved into x[] at the end of the block, behind the framer
@@ -258,76 +390,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
 #pragma unroll
             for (int r = 0; r < PF; ++r) pf[r] = __builtin_nontemporal_load(&nx[gl + LPC * r]);   // read once
         }
-
-        // symbols out (optional)
-        if (sym_out) {
-#pragma unroll
-            for (int r = 0; r < (193 + LPC - 1) / LPC; ++r) {
-                const int q = gl + LPC * r;
-                if (q < n) __builtin_nontemporal_store(my.H[(hp + q) & RM], &sym_out[q]);
-            }
-            sym_out += n;
-        }
-        if (nsyms && gl == 0) nsyms[(size_t)chan * nblk + b] = n;
-        sym_total += n;
-
-        WSTAMP(3);
-        // ---- framer (m17_rx_frame.cpp:126-177) over ring symbols hp .. hp+n-1
-        int pos = (ext_lock >= 0) ? n : 0;
-        while (pos < n) {
-            WCNT(10);
-            if (flock) {
-                const int cnt = min(kFrameSyms - fclk, n - pos);
-                fclk += cnt; pos += cnt;
-                if (fclk == kFrameSyms) {
-                    fclk = 0;
-                    const int fs = hp + pos - kFrameSyms;               // the frame sits in the ring, in place
-                    const SyncResult r = sync_check_lanes8(ring_ld(fs + (gl & 7), hb), sync_sign_mask(gl));
-                    uint32_t flags = 0;
-                    bool parse = false, unlock = false;
-                    if (r.type == 5) { flags |= M17_F_EOT; unlock = true; }
-                    else if (sync_accept(r, true)) { flags |= M17_F_SYNC_OK; parse = true; ferr = 0; }
-                    else {
-                        ferr++;
-                        if (ferr > 5) { flags |= M17_F_LOST; unlock = true; }
-                        else parse = true;
-                    }
-                    if (parse && mode == 1) flags |= M17_F_PARSED;
-                    const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(ferr & 0xFF) << 24);
-                    emit_record_wave(crecs, rec_cap, nrec, gl, w0, flags, r.variance, block_count, (uint32_t)(pos - 1));
-                    if ((flags & M17_F_PARSED) && nrec < rec_cap && r.type >= 1 && r.type <= 3) {
-                        float *fd = fsym + ((size_t)chan * rec_cap + nrec) * kSlotFloats;
-                        store_frame_slot_wave(fd, r.type, gl, rg.w, fs, hb);
-                    }
-                    nrec++;
-                    if (unlock) {
-                        flock = 0;
-                        // reset_sync(): the next hunt windows must see zeros behind them
-                        wave_fence();
-                        if (gl < 8) my.H[(hp + pos - 8 + gl) & RM] = 0.0f;
-                        wave_fence();
-                    }
-                }
-            } else {
-                // hunt: candidate symbol j = pos + lane, window = ring [hp + j - 7, hp + j]
-                SyncResult r;
-                const int l = hunt_pass(pos, n, gl, [&](int i) { return ring_ld(hp + i, hb); }, r);
-                if (l >= 0) {
-                    const int js = pos + l;
-                    // copy_sync(); m_fclk = 8; lock; m17_aos(): the window already is the head of the frame
-                    fclk = 8; ferr = 0; flock = 1;
-                    emit_record_wave(crecs, rec_cap, nrec, gl, (uint32_t)r.type | ((uint32_t)r.votes << 8), M17_F_AOS, r.variance,
-                                     block_count, (uint32_t)js);
-                    nrec++;
-                    pos = js + 1;
-                } else {
-                    pos = min(n, pos + LPC);
-                }
-            }
-        }
-        hp = (hp + n) & RM;
-        if (ext_lock < 0) block_count++;
-        WSTAMP(4);
+        wv_framer_block(t, o, n, b, hb, gl, rg, wst);
 
         // delay line: last 30 inputs; then the prefetched block moves in
         {
@@ -348,19 +411,8 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
     if (chan < 4096 && gl < 8) g_chan_stamps[chan][gl] = wstamps[wave][gl < 7 ? gl : 8];
 #endif
     // ---- store state in the reference's layout
-    const float sum_out = readlane_f(cs_, clane), dif_out = readlane_f(cd_, clane);
-    if (gl == 0) {
-        cs.clk = clk; cs.thr = thr; cs.index = index; cs.sum = sum_out; cs.dif = dif_out; cs.buff[0] = 0.0f;
-        if (ext_lock < 0) {
-            cs.flock = flock; cs.fclk = fclk; cs.ferr = ferr; cs.block_count = block_count; cs.sym_total = sym_total;
-            if (counts) counts[chan] = nrec;
-        }
-    }
+    wv_store_state(t, cs, counts, chan, ext_lock, hb, gl);
     if (gl < kTaps - 1) cs.buff[gl + 1] = my.x[gl];
-    if (ext_lock < 0) {
-        if (flock) { for (int q = gl; q < kFrameSyms; q += LPC) cs.fsym[q] = my.H[(hp - fclk + q) & RM]; }
-        else if (gl < 8) cs.sync[gl] = my.H[(hp - 8 + gl) & RM];
-    }
 }
 
 } // namespace m17dev

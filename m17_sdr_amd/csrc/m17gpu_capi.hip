@@ -5,6 +5,7 @@
 #include "m17_sync_common.hip"
 #include "m17_sync_duo.hip"
 #include "m17_sync_wave.hip"
+#include "m17_fused.hip"
 #include "m17_decode_quad.hip"
 #include "m17_book.hip"
 #include "m17_pluto.hip"
@@ -53,6 +54,8 @@ struct m17gpu_ctx {
     int sync_impl = 0;                       // 0 | 6 = timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond (default);
                                              // 7 = wave per channel at every size
     int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
+    int fir_impl = 0;                        // 0 = by size: the fused FIR-stage kernel (m17_fused.hip) above 1,024 channels, front end +
+                                             // timing kernel up to there; 1 = two kernels at every size; 2 = fused at every size
     std::vector<hipEvent_t> ev_pool;         // 7 events per profiled call: 5 stage marks + call start / end
     std::vector<int> ev_mode;                // mode of each profiled call
 };
@@ -205,6 +208,20 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
         hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(cn, WV_WAVES)), dim3(64 * WV_WAVES), 0, st,
                            disc, offs, state, cn, nblk, mode, ext_lock, recs, recs ? rec_cap : 0,
                            counts, syms, nsyms, fsym, b0, bcount);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+// The FIR stage as ONE kernel (m17_fused.hip): front end, timing loop and framer of a channel in one wave, the
+// discriminator samples never leaving the CU.
+bool use_fused(const m17gpu_ctx *ctx) { return !ctx->afc && (ctx->fir_impl == 2 || (ctx->fir_impl == 0 && ctx->C > 1024)); }
+int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
+                 int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rx_fused, dim3(cdiv(ctx->C, FU_WAVES)), dim3(64 * FU_WAVES), 0, st,
+                       reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->C, nblk, mode,
+                       reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
+                       d_syms, d_nsyms, ctx->d_fsym);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -365,6 +382,10 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
             }
             MARK(1);
             MARK(2);
+        } else if (use_fused(ctx)) {
+            MARK(1);                             // no separate front end: stage 0 reads as zero, stage 1 is the fused kernel
+            if ((rc = launch_fused(ctx, d_iq, nblk, mode, d_recs, rec_cap, d_counts, d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
+            MARK(2);
         } else {
             if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, st)) != M17GPU_OK) return rc;
             MARK(1);
@@ -441,6 +462,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     auto bad = [&]() { return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: value out of range for ") + name); };
     if (!std::strcmp(name, "sync_impl")) { if (value != 0 && value != 6 && value != 7) return bad(); ctx->sync_impl = value; }
     else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 2) return bad(); ctx->fe_impl = value; }
+    else if (!std::strcmp(name, "fir_impl")) { if (value < 0 || value > 2) return bad(); ctx->fir_impl = value; }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
 #ifdef M17_STAMPS
     else if (!std::strcmp(name, "fe_debug")) { ctx->fe_debug = value; }      // instrumented build only: WRONG results
