@@ -146,6 +146,9 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  *                            the filter taps in SGPRs beyond; 7 = that kernel at every size
  *   "fe_impl"            0 = by size (default), 1 = lane per channel-block, 2 = four lanes per
  *                            channel-block
+ *   "fir_impl"           0 | 1 = front end and timing / framer as two kernels (default); 2 = the whole FIR stage
+ *                            of a channel in one wave (k_rx_fused: no discriminator stream in HBM; measured slower,
+ *                            DESIGN.md section 6)
  * and one functional switch:
  *   "afc"                0 (default, as the reference ships: radio.cpp:8) | 1 = radio_set_afc_on(): the
  *                            NCO mixer of m17_dsp.cpp:390-408,468 with the loop of radio.cpp:196-208 per channel.

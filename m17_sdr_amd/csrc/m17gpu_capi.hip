@@ -54,8 +54,8 @@ struct m17gpu_ctx {
     int sync_impl = 0;                       // 0 | 6 = timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond (default);
                                              // 7 = wave per channel at every size
     int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
-    int fir_impl = 0;                        // 0 = by size: the fused FIR-stage kernel (m17_fused.hip) above 1,024 channels, front end +
-                                             // timing kernel up to there; 1 = two kernels at every size; 2 = fused at every size
+    int fir_impl = 0;                        // 0 | 1 = front end + timing kernel (default); 2 = the fused FIR-stage kernel (m17_fused.hip:
+                                             // measured 18 % slower at 16,384 x 12, kept under the parity tests)
     std::vector<hipEvent_t> ev_pool;         // 7 events per profiled call: 5 stage marks + call start / end
     std::vector<int> ev_mode;                // mode of each profiled call
 };
@@ -213,8 +213,8 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
 }
 
 // The FIR stage as ONE kernel (m17_fused.hip): front end, timing loop and framer of a channel in one wave, the
-// discriminator samples never leaving the CU.
-bool use_fused(const m17gpu_ctx *ctx) { return !ctx->afc && (ctx->fir_impl == 2 || (ctx->fir_impl == 0 && ctx->C > 1024)); }
+// discriminator samples never leaving the CU.  Not the default: DESIGN.md section 6 (round 4) has the measurements.
+bool use_fused(const m17gpu_ctx *ctx) { return !ctx->afc && ctx->fir_impl == 2; }
 int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
                  int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st)
 {
