@@ -57,6 +57,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-fir-stage", action="store_true", help="skip the nested configs[1] FIR-stage measurement")
     ap.add_argument("--no-noisy", action="store_true", help="skip the nested measurement on the AWGN workload of configs[3]")
     ap.add_argument("--no-fanout", action="store_true", help="N>1: skip the separately timed RCCL scatter/gather legs")
+    ap.add_argument("--fanout", choices=["torch", "capi"], default=None,
+                    help="transport of the fan-out legs: m17_sdr_amd/shard.py over torch.distributed (default for N>1) or the C-ABI "
+                         "entries of include/m17gpu.h on an ncclComm_t; given explicitly the legs also run at N=1 (degenerate: "
+                         "device copies, every call made)")
     ap.add_argument("--no-syms", action="store_true", help="front end: do not write the symbol stream")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="m17gpu_set_option on the receiver (A/B of bit-identical kernel variants; recorded in config)")
@@ -334,11 +338,65 @@ def host_cores():
     return avail, (len(phys) or None), (threads or None)
 
 
+class CapiFanout:
+    """The C-ABI fan-out entries north_star names (include/m17gpu.h: m17gpu_shard_scatter_iq, m17gpu_pack_records,
+    m17gpu_shard_gather_packed) driven through ctypes with an ncclComm_t of this job's own: rank 0 makes the unique id
+    with RCCL's C API, the process group carries its 128 bytes to the other ranks, every rank joins with
+    ncclCommInitRank -- what a C++ host does with its own bootstrap."""
+
+    def __init__(self, torch, dist, rx, world, rank, dev):
+        import ctypes as C
+        import m17_sdr_amd as m
+        self.C, self.torch, self.rx, self.world, self.rank, self.lib = C, torch, rx, world, rank, m.lib()
+        self.rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+        class UID(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid = UID()
+        if rank == 0 and self.rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        if world > 1:
+            t = torch.frombuffer(bytearray(bytes(uid.internal) if rank == 0 else bytes(128)), dtype=torch.uint8).to(dev)
+            dist.broadcast(t, src=0)
+            C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        self.comm = C.c_void_p()
+        self.rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+        if self.rccl.ncclCommInitRank(C.byref(self.comm), world, uid, rank) != 0:
+            raise RuntimeError("ncclCommInitRank failed")
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.m17gpu_last_error().decode()}")
+
+    def scatter(self, full, total, nblk, mine, stream):
+        self._chk(self.lib.m17gpu_shard_scatter_iq(self.rx._ctx, self.comm, self.rank, self.world, 0,
+                                                   full.data_ptr() if full is not None else None, total, nblk, mine.data_ptr(),
+                                                   self.C.c_void_p(stream.cuda_stream)), "m17gpu_shard_scatter_iq")
+
+    def gather(self, packed, offs, total, packed_all, offs_all, stream):
+        totals = (self.C.c_int32 * self.world)()
+        self._chk(self.lib.m17gpu_shard_gather_packed(self.rx._ctx, self.comm, self.rank, self.world, 0, packed.data_ptr(), offs.data_ptr(),
+                                                      total, packed_all.data_ptr() if packed_all is not None else None,
+                                                      int(packed_all.shape[0]) if packed_all is not None else 0,
+                                                      offs_all.data_ptr() if offs_all is not None else None, totals,
+                                                      self.C.c_void_p(stream.cuda_stream)), "m17gpu_shard_gather_packed")
+        return list(totals)
+
+    def close(self):
+        if self.comm:
+            self.rccl.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
 def fanout_legs(args, torch, dist, rx, out, iq_step, world, rank, backend, C, nblk, mode):
     """SURVEY 8(e) "with fan-out": rank 0 holds the IQ of all world x C channels of one step and fans it out to the
-    owning ranks point to point (shard.scatter_iq: one send per peer, xGMI is a full mesh); every rank runs the step;
-    the 64-byte records come back to rank 0 (shard.gather_records).  RCCL moves device tensors; under the gloo
-    rehearsal backend the same calls stage through host memory.  Timed apart from the compute-only region."""
+    owning ranks point to point (one send per peer, xGMI is a full mesh); every rank runs the step; the step's records
+    are packed on the device (valid rows only: m17gpu_pack_records) and come back to rank 0 with their offset tables.
+    Two transports: `torch` = m17_sdr_amd/shard.py over torch.distributed (RCCL for device tensors; under the gloo
+    rehearsal backend the same calls stage through host memory), `capi` = the C-ABI entries of include/m17gpu.h on an
+    ncclComm_t of the job's own.  Timed apart from the compute-only region, leg by leg; then the same step
+    double-buffered -- the scatter of step k+1 on a second stream beside the compute of step k -- as
+    `with_fanout_overlapped`."""
     from m17_sdr_amd import shard
     dev = torch.device("cuda", rx.device)
     total = world * C
@@ -346,17 +404,27 @@ def fanout_legs(args, torch, dist, rx, out, iq_step, world, rank, backend, C, nb
     reps = 5
     t_sc, t_cp, t_ga = [], [], []
     flag_dev = dev if backend == "nccl" else "cpu"
+    transport = args.fanout or "torch"
+    if transport == "capi" and backend != "nccl":
+        transport = "torch"                      # the C-ABI entries move device memory over RCCL only
 
     def all_ok(err):
         """A leg that failed on ANY rank ends the legs on EVERY rank: one rank leaving alone would strand its peers
         in a recv or a barrier until the process-group timeout."""
+        if world == 1:
+            return err is None
         f = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=flag_dev)
         dist.all_reduce(f, op=dist.ReduceOp.MAX)
         return int(f.item()) == 0
 
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
     # what can fail on ONE rank alone (building the staging tensor, a bad argument) is agreed on before any rank enters
     # the transfer: a peer already blocked in a matching send / recv could not be told afterwards
-    err = None
+    err, capi = None, None
     try:
         if os.environ.get("M17_BENCH_INJECT_FANOUT_FAILURE") == str(rank):           # test hook (tests/test_a_bench_ranks.py)
             raise RuntimeError("injected fan-out failure")
@@ -364,39 +432,98 @@ def fanout_legs(args, torch, dist, rx, out, iq_step, world, rank, backend, C, nb
             time.sleep(3600)
         if rank == 0:
             full = iq_step.repeat(world, 1, 1, 1) if world > 1 else iq_step         # content is irrelevant to the transfer
+        if transport == "capi":
+            capi = CapiFanout(torch, dist, rx, world, rank, dev)
     except Exception as e:                                       # noqa: BLE001 -- reported in the line
         err = f"fan-out set-up on rank {rank}: {type(e).__name__}: {e}"[:300]
     if not all_ok(err):
         return {"fanout_error": err or "fan-out set-up failed on another rank"}
 
+    main = torch.cuda.current_stream(dev)
+    cap = int(out["rec_cap"])
+    packed = torch.empty((C * cap, 64), dtype=torch.uint8, device=dev)
+    offs = torch.empty((C + 1,), dtype=torch.int32, device=dev)
+    packed_all = torch.empty((total * cap, 64), dtype=torch.uint8, device=dev) if (capi and rank == 0) else None
+    offs_all = torch.empty((total + 1,), dtype=torch.int32, device=dev) if (capi and rank == 0) else None
+    shards = [torch.empty((C, nblk, 1920, 2), dtype=torch.int16, device=dev) for _ in range(2)]
+    rec_rows = [0]
+
+    def scatter(stream, k):
+        if capi:
+            capi.scatter(full, total, nblk, shards[k % 2], stream)
+            return shards[k % 2]
+        with torch.cuda.stream(stream):
+            mine = shard.scatter_iq(full, total, nblk, src=0, device=dev) if world > 1 else full
+        mine.record_stream(main)
+        return mine
+
+    def gather():
+        rx.pack_records(out, packed, offs)
+        if capi:
+            tot = capi.gather(packed, offs, total, packed_all, offs_all, main)
+            rec_rows[0] = tot[rank] if rank == 0 else int(offs[-1].item())
+        elif world > 1:
+            _, _, tot = shard.gather_packed(packed, offs, dst=0)
+            rec_rows[0] = tot[rank] if tot else int(offs[-1].item())
+        else:
+            rec_rows[0] = int(offs[-1].item())
+
     for _ in range(reps + 1):
-        torch.cuda.synchronize(dev); dist.barrier(); t0 = time.perf_counter()
+        barrier(); t0 = time.perf_counter()
         err, mine = None, None
         try:
-            mine = shard.scatter_iq(full, total, nblk, src=0, device=dev)
+            mine = scatter(main, 0)
         except Exception as e:                                   # noqa: BLE001 -- reported in the line
-            err = f"scatter_iq: {type(e).__name__}: {e}"[:300]
+            err = f"scatter: {type(e).__name__}: {e}"[:300]
         if not all_ok(err):
-            return {"fanout_error": err or "scatter_iq failed on another rank"}
-        torch.cuda.synchronize(dev); dist.barrier(); t1 = time.perf_counter()
+            return {"fanout_error": err or "the scatter failed on another rank"}
+        barrier(); t1 = time.perf_counter()
         rx.rx_blocks(mine, mode, out)
-        torch.cuda.synchronize(dev); dist.barrier(); t2 = time.perf_counter()
+        barrier(); t2 = time.perf_counter()
         try:
-            shard.gather_records(out["recs"], out["counts"], dst=0)
+            gather()
         except Exception as e:                                   # noqa: BLE001
-            err = f"gather_records: {type(e).__name__}: {e}"[:300]
+            err = f"gather: {type(e).__name__}: {e}"[:300]
         if not all_ok(err):
-            return {"fanout_error": err or "gather_records failed on another rank"}
-        torch.cuda.synchronize(dev); dist.barrier(); t3 = time.perf_counter()
+            return {"fanout_error": err or "the gather failed on another rank"}
+        barrier(); t3 = time.perf_counter()
         t_sc.append(t1 - t0); t_cp.append(t2 - t1); t_ga.append(t3 - t2)
-    vals = torch.tensor([sum(t_sc[1:]) / reps, sum(t_cp[1:]) / reps, sum(t_ga[1:]) / reps], dtype=torch.float64,
-                        device=dev if backend == "nccl" else "cpu")
-    dist.all_reduce(vals, op=dist.ReduceOp.MAX)
-    sc, cp, ga = (float(v) * 1e3 for v in vals.tolist())
+
+    # double-buffered: the scatter of step k+1 on a second stream beside the compute (and the gather) of step k
+    t_ov, err = None, None
+    try:
+        side = torch.cuda.Stream(device=dev)
+        nxt = scatter(main, 0)
+        barrier(); t0 = time.perf_counter()
+        for k in range(reps):
+            cur = nxt
+            side.wait_stream(main)                               # buffer k+1 was last read two steps ago, on main
+            nxt = scatter(side, k + 1)
+            rx.rx_blocks(cur, mode, out)
+            gather()
+            main.wait_stream(side)
+        barrier(); t_ov = (time.perf_counter() - t0) / reps
+    except Exception as e:                                       # noqa: BLE001
+        err = f"overlapped leg: {type(e).__name__}: {e}"[:300]
+    if not all_ok(err):
+        t_ov = None
+    vals = torch.tensor([sum(t_sc[1:]) / reps, sum(t_cp[1:]) / reps, sum(t_ga[1:]) / reps, t_ov if t_ov is not None else -1.0],
+                        dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+    sc, cp, ga, ov = (float(v) * 1e3 for v in vals.tolist())
+    if capi:
+        capi.close()
+    rec_bytes = rec_rows[0] * 64 + (C + 1) * 4
     return {"fanout_ms": round(sc, 4), "gather_ms": round(ga, 4), "compute_ms_in_this_leg": round(cp, 4),
-            "iq_bytes_per_peer": C * nblk * 7680, "records_bytes_per_rank": int(out["recs"].numel()),
+            "overlapped_ms_per_step": round(ov, 4) if ov > 0 else None,
+            "iq_bytes_per_peer": C * nblk * 7680, "records_bytes_per_rank": rec_bytes,
+            "records_bytes_unpacked": int(out["recs"].numel()) + 4 * C,
             "scatter_GBps_from_root": round((world - 1) * C * nblk * 7680 / (sc * 1e-3) / 1e9, 2) if world > 1 and sc > 0 else None,
-            "reps": reps, "transport": "RCCL point-to-point send/recv + gather" if backend == "nccl" else f"{backend} (rehearsal, staged through host)"}
+            "reps": reps,
+            "transport": ("C-ABI m17gpu_shard_scatter_iq / m17gpu_pack_records / m17gpu_shard_gather_packed on an ncclComm_t (RCCL)" if capi
+                          else "m17_sdr_amd.shard over torch.distributed: RCCL point-to-point" if backend == "nccl"
+                          else f"m17_sdr_amd.shard over torch.distributed: {backend} (rehearsal, staged through host)")}
 
 
 def run_rank(args):
@@ -480,7 +607,7 @@ def run_rank(args):
     if args.option:
         line["config"]["options"] = list(args.option)
     fan = None
-    if world > 1 and not args.no_fanout:
+    if (world > 1 or args.fanout) and not args.no_fanout:
         # After the timed region and outside `value`: neither a failure nor a HANG of the transfer legs may cost the
         # measurement.  A collective that never returns cannot be cancelled, so a watchdog prints the line as it stands
         # (rank 0) and ends the process on every rank when the legs overrun their allowance.
@@ -508,7 +635,12 @@ def run_rank(args):
     if fan is not None and "fanout_ms" in fan:
         wf = ms_step + fan["fanout_ms"] + fan["gather_ms"]
         line["with_fanout"] = {"ms_per_step": round(wf, 4), "value": round(world * C * nblk * 192 / (wf * 1e-3) / 1e6, 3),
-                               "unit": "Msym/s", "note": "compute step + RCCL scatter of the IQ from rank 0 + gather of the records, not overlapped"}
+                               "unit": "Msym/s", "note": "compute step + scatter of the IQ from rank 0 + gather of the packed records, one after the other"}
+        if fan.get("overlapped_ms_per_step"):
+            wo = fan["overlapped_ms_per_step"]
+            line["with_fanout_overlapped"] = {"ms_per_step": round(wo, 4), "value": round(world * C * nblk * 192 / (wo * 1e-3) / 1e6, 3),
+                                              "unit": "Msym/s", "note": "double-buffered: the scatter of step k+1 on a second stream beside "
+                                                                         "the compute and the packed gather of step k"}
     if rank == 0:
         rx.close()
         del iq

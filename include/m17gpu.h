@@ -238,6 +238,28 @@ int m17gpu_shard_gather_records(m17gpu_ctx *ctx, void *comm, int rank, int world
                                 const m17gpu_rec *d_recs_mine, const int32_t *d_counts_mine, int rec_cap,
                                 int n_channels_total, m17gpu_rec *d_recs_all, int32_t *d_counts_all, void *stream);
 
+/* Packed gather (what SURVEY 8e budgets: about 1 MB per GPU per step).  m17gpu_rx_blocks leaves recs [C][rec_cap] with
+ * counts [C] valid rows; only the valid rows need to cross xGMI:
+ *   m17gpu_pack_records         d_offsets [C+1] = exclusive scan of the counts (d_offsets[C] = records in this step),
+ *                               d_packed [packed_cap] = the valid records, channel-major, event order inside a channel.
+ *                               Enqueued on `stream`, nothing read back.
+ *   m17gpu_shard_gather_packed  every rank's packed rows land on dst_rank in d_packed_all, rank after rank, with
+ *                               d_offsets_all [n_channels_total + 1] the GLOBAL offsets (channel c of the node: rows
+ *                               d_offsets_all[c] .. d_offsets_all[c+1]); h_totals [world] (host, may be NULL) the
+ *                               records per rank.  Two grouped exchanges: the offset tables, then sum(counts) x 64 B
+ *                               per rank.  The sizes of the second come from the first, so the entry synchronises
+ *                               `stream` (twice on dst_rank); it runs behind the step, beside nothing.
+ *   m17gpu_unpack_records       packed rows + offsets back into recs [n_channels][rec_cap] + counts (rows beyond a
+ *                               channel's count zeroed): the layout m17gpu_rx_blocks writes, for callers that want it.
+ * (The reference has nothing to gather: one channel per process, m17_tx_rx.cpp:28-40.) */
+int m17gpu_pack_records(m17gpu_ctx *ctx, const m17gpu_rec *d_recs, int rec_cap, const int32_t *d_counts,
+                        m17gpu_rec *d_packed, int packed_cap, int32_t *d_offsets, void *stream);
+int m17gpu_unpack_records(m17gpu_ctx *ctx, const m17gpu_rec *d_packed, const int32_t *d_offsets, int n_channels,
+                          m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, void *stream);
+int m17gpu_shard_gather_packed(m17gpu_ctx *ctx, void *comm, int rank, int world, int dst_rank,
+                               const m17gpu_rec *d_packed_mine, const int32_t *d_offsets_mine, int n_channels_total,
+                               m17gpu_rec *d_packed_all, int packed_cap_all, int32_t *d_offsets_all, int32_t *h_totals, void *stream);
+
 /* ---------------- output wire format on the device ----------------
  * m17gpu_set_net_output attaches the sink of decode_stream_frame (m17_rx_parse.cpp:151-154 ->
  * m17_net_new_rx_data m17_net.cpp:53-74) to the context: while d_net != NULL every m17gpu_rx_blocks(mode 1)

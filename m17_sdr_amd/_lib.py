@@ -70,6 +70,9 @@ SIGNATURES = {
     "m17gpu_get_constant": (_i, [C.c_char_p, _vp, _i]),
     "m17gpu_format_net_frame": (_i, [C.c_uint16, _vp, C.c_uint16, _vp, _u64, _vp]),
     "m17gpu_parse_lsf": (_i, [_vp, _vp]),
+    "m17gpu_pack_records": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "m17gpu_unpack_records": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "m17gpu_shard_gather_packed": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "m17gpu_set_net_output": (_i, [_vp, _vp, _i, _vp, _u64]),
     "m17gpu_shard_range": (None, [_i, _i, _i, _vp, _vp]),
     "m17gpu_shard_scatter_iq": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),

@@ -209,6 +209,35 @@ class Receiver:
         _check(lib().m17gpu_golay_decode(self._ctx, _ptr(words), _ptr(out), n, self._stream()), "m17gpu_golay_decode")
         return out
 
+    # ---- record compaction for the multi-GPU gather ---------------
+    def pack_records(self, out, packed=None, offsets=None):
+        """The valid records of a step, channel-major: (packed uint8 [C*rec_cap, 64] -- rows [0, offsets[C]) are valid --,
+        offsets int32 [C+1]); device tensors, nothing is read back (m17gpu_pack_records)."""
+        import torch
+        cap = int(out["rec_cap"])
+        dev = out["recs"].device
+        if packed is None:
+            packed = torch.empty((self.C * cap, 64), dtype=torch.uint8, device=dev)
+        if offsets is None:
+            offsets = torch.empty((self.C + 1,), dtype=torch.int32, device=dev)
+        self._chk(out["recs"], torch.uint8, (self.C, cap, 64), "out['recs']")
+        self._chk(offsets, torch.int32, (self.C + 1,), "offsets")
+        if packed.dtype != torch.uint8 or packed.dim() != 2 or packed.shape[1] != 64 or not packed.is_contiguous():
+            raise ValueError("packed must be a contiguous uint8 tensor [rows, 64]")
+        _check(lib().m17gpu_pack_records(self._ctx, _ptr(out["recs"]), cap, _ptr(out["counts"]), _ptr(packed),
+                                         int(packed.shape[0]), _ptr(offsets), self._stream()), "m17gpu_pack_records")
+        return packed, offsets
+
+    def unpack_records(self, packed, offsets, rec_cap):
+        """Packed rows + offsets [n+1] back into (recs [n, rec_cap, 64], counts [n]) -- the layout rx_blocks writes."""
+        import torch
+        n = int(offsets.shape[0]) - 1
+        recs = torch.empty((n, int(rec_cap), 64), dtype=torch.uint8, device=packed.device)
+        counts = torch.empty((n,), dtype=torch.int32, device=packed.device)
+        _check(lib().m17gpu_unpack_records(self._ctx, _ptr(packed), _ptr(offsets), n, _ptr(recs), int(rec_cap), _ptr(counts),
+                                           self._stream()), "m17gpu_unpack_records")
+        return recs, counts
+
     # ---- output wire format on the device (SURVEY 8f-3) -----------------------
     def set_net_output(self, rec_cap=None, stream_ids=None, dst_override=0):
         """Attach the network sink: returns the uint8 tensor [C, rec_cap, 56] that rx_blocks(mode 1) fills with the

@@ -321,6 +321,8 @@ __device__ __forceinline__ void wv_store_state(const WvCtl &t, ChanState &cs, in
     }
 }
 
+// (six waves per SIMD: a seventh -- 72 VGPRs, amdgpu_waves_per_eu(7, 7), 16 B of scratch -- changes nothing, 0.294-0.303 against
+//  0.302 ms on one box, round 4; eight with 14 VGPRs in scratch are slower, round 3)
 __global__ __launch_bounds__(64 * WV_WAVES, 6)
 void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                        const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)

@@ -8,6 +8,7 @@
 #include "m17_fused.hip"
 #include "m17_decode_quad.hip"
 #include "m17_book.hip"
+#include "m17_pack.hip"
 #include "m17_pluto.hip"
 #include "m17_gen.hip"
 #include "m17_host.h"
@@ -630,6 +631,126 @@ int m17gpu_shard_gather_records(m17gpu_ctx *ctx, void *comm, int rank, int world
         HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(d_recs_all) + (size_t)lo * per, d_recs_mine, (size_t)(hi - lo) * per,
                               hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(d_counts_all + lo, d_counts_mine, (size_t)(hi - lo) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    }
+    return M17GPU_OK;
+}
+
+// Valid records only, channel-major (m17_pack.hip): d_offsets [C+1] (d_offsets[C] = number of records),
+// d_packed [packed_cap] records.  Everything is enqueued on `stream`; nothing is read back.
+int m17gpu_pack_records(m17gpu_ctx *ctx, const m17gpu_rec *d_recs, int rec_cap, const int32_t *d_counts,
+                        m17gpu_rec *d_packed, int packed_cap, int32_t *d_offsets, void *stream)
+{
+    if (!ctx || !d_recs || !d_counts || !d_packed || !d_offsets || rec_cap <= 0 || packed_cap <= 0)
+        return fail(M17GPU_ERR_ARG, "m17gpu_pack_records: bad argument");
+    ON_CTX_DEVICE(ctx);
+    hipStream_t st = S(stream);
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, st, d_counts, ctx->C, rec_cap, d_offsets);
+    const long long pieces = (long long)ctx->C * rec_cap * 4;
+    hipLaunchKernelGGL(k_pack_copy, dim3(cdiv(pieces, 256)), dim3(256), 0, st, reinterpret_cast<const uint4 *>(d_recs), ctx->C,
+                       rec_cap, d_offsets, reinterpret_cast<uint4 *>(d_packed), packed_cap);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+int m17gpu_unpack_records(m17gpu_ctx *ctx, const m17gpu_rec *d_packed, const int32_t *d_offsets, int n_channels,
+                          m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, void *stream)
+{
+    if (!ctx || !d_packed || !d_offsets || !d_recs || !d_counts || rec_cap <= 0 || n_channels <= 0)
+        return fail(M17GPU_ERR_ARG, "m17gpu_unpack_records: bad argument");
+    ON_CTX_DEVICE(ctx);
+    const long long pieces = (long long)n_channels * rec_cap * 4;
+    hipLaunchKernelGGL(k_unpack_copy, dim3(cdiv(pieces, 256)), dim3(256), 0, S(stream), reinterpret_cast<const uint4 *>(d_packed),
+                       n_channels, rec_cap, d_offsets, reinterpret_cast<uint4 *>(d_recs), d_counts);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
+// The gather of a step's records in packed form: every rank has run m17gpu_pack_records (d_packed_mine, d_offsets_mine
+// [C+1]); dst_rank receives d_packed_all (all ranks' records, rank after rank, channel-major) and d_offsets_all
+// [n_channels_total + 1] (global: channel c's records are rows d_offsets_all[c] .. d_offsets_all[c+1]).  What crosses the
+// links is sum(counts) x 64 B + 4 B per channel -- about 1 MB per 16,384 channels x 12 blocks, where the unpacked
+// [C][2 nblk + 2] array is 27 MB.  The row counts size the transfers, so this entry synchronises `stream` twice (each
+// rank reads back its own total; the gathering rank the others' totals): it runs after the step, beside nothing.
+// h_totals [world] (host, may be NULL) receives the per-rank record counts on dst_rank.
+int m17gpu_shard_gather_packed(m17gpu_ctx *ctx, void *comm, int rank, int world, int dst_rank,
+                               const m17gpu_rec *d_packed_mine, const int32_t *d_offsets_mine, int n_channels_total,
+                               m17gpu_rec *d_packed_all, int packed_cap_all, int32_t *d_offsets_all, int32_t *h_totals, void *stream)
+{
+    if (!ctx || !comm || world <= 0 || rank < 0 || rank >= world || dst_rank < 0 || dst_rank >= world || n_channels_total <= 0 ||
+        !d_packed_mine || !d_offsets_mine || (rank == dst_rank && (!d_packed_all || !d_offsets_all || packed_cap_all <= 0)))
+        return fail(M17GPU_ERR_ARG, "m17gpu_shard_gather_packed: bad argument");
+    int lo, hi;
+    m17gpu_shard_range(rank, world, n_channels_total, &lo, &hi);
+    if (hi - lo != ctx->C) return fail(M17GPU_ERR_ARG, "m17gpu_shard_gather_packed: the context does not hold this rank's channel range");
+    const RcclApi &R = rccl();
+    if (!R.ok) return fail(M17GPU_ERR_HIP, "m17gpu_shard_gather_packed: no RCCL library in this process (librccl.so.1)");
+    ON_CTX_DEVICE(ctx);
+    hipStream_t st = S(stream);
+    ncclComm_t cm = static_cast<ncclComm_t>(comm);
+    std::string grp_err;
+    // leg 1: the local offset tables ([Cr + 1] int32 each) to the gathering rank, behind one another
+    RCCLCHK(R.GroupStart());
+    if (rank == dst_rank) {
+        for (int r = 0; r < world; ++r) {
+            int a, b;
+            m17gpu_shard_range(r, world, n_channels_total, &a, &b);
+            if (r == dst_rank || b <= a) continue;
+            RCCLGRP(R.Recv(d_offsets_all + a + 1, (size_t)(b - a), ncclInt32, r, cm, st));      // local offs[1 .. Cr]; shifted below
+        }
+    } else if (hi > lo) {
+        RCCLGRP(R.Send(d_offsets_mine + 1, (size_t)(hi - lo), ncclInt32, dst_rank, cm, st));
+    }
+    RCCLGRP(R.GroupEnd());
+    if (!grp_err.empty()) return fail(M17GPU_ERR_HIP, grp_err);
+    int32_t mine_total = 0;
+    HIPCHK(hipMemcpyAsync(&mine_total, d_offsets_mine + (hi - lo), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    std::vector<int32_t> totals((size_t)world, 0);
+    if (rank == dst_rank) {
+        if (hi > lo) HIPCHK(hipMemcpyAsync(d_offsets_all + lo + 1, d_offsets_mine + 1, (size_t)(hi - lo) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        for (int r = 0; r < world; ++r) {                       // each rank's total = its last local offset
+            int a, b;
+            m17gpu_shard_range(r, world, n_channels_total, &a, &b);
+            if (b > a) HIPCHK(hipMemcpyAsync(&totals[r], d_offsets_all + b, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    if (rank != dst_rank) totals[rank] = mine_total;
+    // leg 2: the records themselves, sum(counts) rows per rank
+    long long base = 0;
+    if (rank == dst_rank) {
+        long long sum = 0;
+        for (int r = 0; r < world; ++r) sum += totals[r];
+        if (sum > packed_cap_all) return fail(M17GPU_ERR_ARG, "m17gpu_shard_gather_packed: d_packed_all is too small for this step's records");
+    }
+    RCCLCHK(R.GroupStart());
+    if (rank == dst_rank) {
+        for (int r = 0; r < world; ++r) {
+            if (r != dst_rank && totals[r] > 0)
+                RCCLGRP(R.Recv(reinterpret_cast<char *>(d_packed_all) + (size_t)base * sizeof(m17gpu_rec), (size_t)totals[r] * sizeof(m17gpu_rec),
+                               ncclChar, r, cm, st));
+            base += totals[r];
+        }
+    } else if (mine_total > 0) {
+        RCCLGRP(R.Send(d_packed_mine, (size_t)mine_total * sizeof(m17gpu_rec), ncclChar, dst_rank, cm, st));
+    }
+    RCCLGRP(R.GroupEnd());
+    if (!grp_err.empty()) return fail(M17GPU_ERR_HIP, grp_err);
+    if (rank == dst_rank) {
+        // own rows, and every rank's local offsets moved behind the ranks before it
+        long long before = 0;
+        HIPCHK(hipMemsetAsync(d_offsets_all, 0, sizeof(int32_t), st));
+        for (int r = 0; r < world; ++r) {
+            int a, b;
+            m17gpu_shard_range(r, world, n_channels_total, &a, &b);
+            if (r == dst_rank && totals[r] > 0)
+                HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(d_packed_all) + (size_t)before * sizeof(m17gpu_rec), d_packed_mine,
+                                      (size_t)totals[r] * sizeof(m17gpu_rec), hipMemcpyDeviceToDevice, st));
+            if (b > a && before > 0)
+                hipLaunchKernelGGL(k_offs_shift, dim3(cdiv(b - a, 256)), dim3(256), 0, st, d_offsets_all + a, b - a, (int)before);
+            before += totals[r];
+        }
+        HIPCHK(hipGetLastError());
+        if (h_totals) std::memcpy(h_totals, totals.data(), sizeof(int32_t) * (size_t)world);
     }
     return M17GPU_OK;
 }

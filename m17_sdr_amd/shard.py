@@ -7,8 +7,11 @@ The only exchanges are at the edges of a step, both point-to-point from / to one
     scatter_iq      the IQ of all channels fans out from the ingest rank, one send per peer (xGMI is a
                     full mesh: 7 links x ~153 GB/s, so 7 direct sends run on 7 links; a ring would be
                     per-link bound for no benefit)
-    gather_records  the 64-byte decoded-frame records come back (about 1 MB per 16,384 channels per
-                    step against 125.8 MB of IQ per block)
+    gather_packed   the 64-byte decoded-frame records come back, valid rows only (Receiver.pack_records /
+                    m17gpu_pack_records first): about 1 MB per 16,384 channels x 12 blocks against
+                    125.8 MB of IQ per block
+    gather_records  the same for the unpacked [C, cap, 64] array (27 MB at that size): kept for callers that
+                    hold no packed form
 
 With the "nccl" backend (= RCCL on ROCm) device tensors move GPU to GPU.  Backends that cannot move
 device tensors (gloo: CPU tests, and the 1-GPU rehearsal of bench.py) stage through host memory; the
@@ -54,6 +57,61 @@ def gather_records(recs, counts, dst=0, group=None):
         return None, None
     return (torch.cat([out_r[r][:sizes[r]] for r in range(world)]).to(home),
             torch.cat([out_c[r][:sizes[r]] for r in range(world)]).to(home))
+
+
+def gather_packed(packed, offsets, dst=0, group=None):
+    """Gather the PACKED records of a step to `dst`: packed [rows, 64] uint8 whose first offsets[-1] rows are valid,
+    offsets [Cr + 1] int32 (exclusive scan of the rank's per-channel counts).  Two exchanges: the offset tables
+    (4 bytes per channel) and sum(counts) x 64 bytes per rank -- nothing of the unused record capacity moves.  The row
+    counts size the second exchange, so every rank reads its own total back (one host sync per step, behind the step).
+    Returns (packed_all [sum, 64], offsets_all [C + 1] GLOBAL offsets, totals list) on dst, (None, None, None) elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    home = packed.device
+    direct = _moves_device_tensors(group) or home.type == "cpu"
+    wire = home if direct else torch.device("cpu")
+    n_mine = int(offsets[-1].item())
+    meta = torch.tensor([offsets.shape[0] - 1, n_mine], dtype=torch.int64, device=wire)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    chans = [int(t[0].item()) for t in metas]
+    totals = [int(t[1].item()) for t in metas]
+    ops, keep = [], []
+    if rank == dst:
+        offs_all = torch.zeros((sum(chans) + 1,), dtype=torch.int32, device=wire)
+        rows_all = torch.empty((sum(totals), 64), dtype=torch.uint8, device=wire)
+        c0 = r0 = 0
+        for r in range(world):
+            o_r = offs_all[c0 + 1:c0 + 1 + chans[r]]
+            p_r = rows_all[r0:r0 + totals[r]]
+            if r == rank:
+                o_r.copy_(offsets[1:].to(wire))
+                p_r.copy_(packed[:n_mine].to(wire))
+            else:
+                if chans[r]:
+                    ops.append(dist.P2POp(dist.irecv, o_r, r, group))
+                if totals[r]:
+                    ops.append(dist.P2POp(dist.irecv, p_r, r, group))
+            c0 += chans[r]
+            r0 += totals[r]
+    else:
+        if chans[rank]:
+            keep.append(offsets[1:].to(wire).contiguous())
+            ops.append(dist.P2POp(dist.isend, keep[-1], dst, group))
+        if n_mine:
+            keep.append(packed[:n_mine].to(wire).contiguous())
+            ops.append(dist.P2POp(dist.isend, keep[-1], dst, group))
+    for q in (dist.batch_isend_irecv(ops) if ops else []):
+        q.wait()
+    if rank != dst:
+        return None, None, None
+    # local offsets -> global: every rank's table moves behind the rows of the ranks before it
+    c0 = r0 = 0
+    for r in range(world):
+        offs_all[c0 + 1:c0 + 1 + chans[r]] += r0
+        c0 += chans[r]
+        r0 += totals[r]
+    return rows_all.to(home), offs_all.to(home), totals
 
 
 def scatter_iq(iq_full, n_channels, nblk, src=0, group=None, device=None):

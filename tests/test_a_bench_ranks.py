@@ -30,6 +30,30 @@ def test_bench_starts_its_own_ranks_gloo_rehearsal():
     assert line["config"]["channels_total"] == 192 and line["value"] > 0
     assert line["fanout"]["fanout_ms"] > 0 and line["fanout"]["gather_ms"] > 0
     assert line["roofline"]["calls_timed"] == 4 and line["roofline"]["frac"] > 0
+    # the gather ships content, not capacity: the valid rows + 4 bytes per channel
+    fan = line["fanout"]
+    assert 96 * 4 < fan["records_bytes_per_rank"] < fan["records_bytes_unpacked"] * 6 // 10, fan
+    assert line["with_fanout"]["ms_per_step"] > 0 and line["with_fanout_overlapped"]["ms_per_step"] > 0
+
+
+def test_bench_drives_the_capi_fanout_entries():
+    """`bench.py --fanout capi`: the legs go through the C-ABI entries north_star names (m17gpu_shard_scatter_iq,
+    m17gpu_pack_records, m17gpu_shard_gather_packed) on an ncclComm_t made with RCCL's C API.  One GPU = one rank: the
+    communicator, every call and the stream plumbing of the double-buffered leg are exercised; the sends themselves
+    need a second GPU (no multi-GPU box has been available in any round)."""
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "M17_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--channels", "128", "--blocks", "6", "--no-cpu-baseline", "--no-noisy", "--no-fir-stage", "--fanout", "capi"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    fan = line["fanout"]
+    assert "fanout_error" not in fan, fan
+    assert fan["transport"].startswith("C-ABI") and fan["fanout_ms"] > 0 and fan["gather_ms"] > 0
+    assert 128 * 4 < fan["records_bytes_per_rank"] < fan["records_bytes_unpacked"] * 6 // 10
+    assert line["with_fanout_overlapped"]["ms_per_step"] > 0
 
 
 def test_bench_line_survives_a_failing_fanout_leg():
@@ -140,6 +164,29 @@ def test_capi_fanout_entries_with_a_one_rank_rccl_communicator():
         recs = allr.cpu().numpy().view(oracle.REC_DTYPE).reshape(Cn, -1)
         for c in range(Cn):
             assert recs[c, :ref["counts"][c]].tobytes() == ref["recs"][c, :ref["counts"][c]].tobytes()
+        # the packed form: m17gpu_pack_records, m17gpu_shard_gather_packed, m17gpu_unpack_records against the oracle
+        packed, offs = rx.pack_records(out)
+        pall = torch.zeros_like(packed)
+        oall = torch.full((Cn + 1,), -1, dtype=torch.int32, device="cuda")
+        totals = (C.c_int32 * 1)()
+        rc = lib.m17gpu_shard_gather_packed(rx._ctx, comm, 0, 1, 0, p(packed), p(offs), Cn, p(pall), int(pall.shape[0]), p(oall), totals, st)
+        assert rc == 0, lib.m17gpu_last_error()
+        torch.cuda.synchronize()
+        want_offs = np.concatenate([[0], np.cumsum(ref["counts"])]).astype(np.int32)
+        np.testing.assert_array_equal(oall.cpu().numpy(), want_offs)
+        np.testing.assert_array_equal(offs.cpu().numpy(), want_offs)
+        assert totals[0] == want_offs[-1] > 0
+        rows = pall.cpu().numpy()
+        for c in range(Cn):
+            assert rows[want_offs[c]:want_offs[c + 1]].tobytes() == ref["recs"][c, :ref["counts"][c]].tobytes()
+        ur, uc = rx.unpack_records(pall, oall, out["rec_cap"])
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(uc.cpu().numpy(), ref["counts"])
+        ur = ur.cpu().numpy().view(oracle.REC_DTYPE).reshape(Cn, -1)
+        for c in range(Cn):
+            assert ur[c, :ref["counts"][c]].tobytes() == ref["recs"][c, :ref["counts"][c]].tobytes() and not ur[c, ref["counts"][c]:].view(np.uint8).any()
+        # a destination too small for the step's records is refused, not overrun
+        assert lib.m17gpu_shard_gather_packed(rx._ctx, comm, 0, 1, 0, p(packed), p(offs), Cn, p(pall), 3, p(oall), None, st) != 0
         # a context that does not hold the rank's range is refused
         assert lib.m17gpu_shard_scatter_iq(rx._ctx, comm, 0, 2, 0, p(full), Cn, nblk, p(mine), st) != 0
         rx.close()

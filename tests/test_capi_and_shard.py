@@ -70,7 +70,7 @@ _WORKER = r"""
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["M17_ROOT"])
 import m17_sdr_amd as m
-from m17_sdr_amd.shard import channel_range, gather_records, scatter_iq
+from m17_sdr_amd.shard import channel_range, gather_packed, gather_records, scatter_iq
 from tests import oracle
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -91,6 +91,20 @@ if rank == 0:
     assert np.array_equal(gc.numpy(), whole["counts"])
     assert gr.numpy().tobytes() == whole["recs"].view(np.uint8).tobytes()
     print("GATHER_OK", int(gc.sum()))
+# the packed form (what bench.py and a C++ host gather): valid rows only, channel-major, + exclusive-scan offsets --
+# packed here as m17gpu_pack_records packs on the device
+offs = torch.from_numpy(np.concatenate([[0], np.cumsum(ref["counts"])]).astype(np.int32))
+rows = np.concatenate([ref["recs"][c, :ref["counts"][c]] for c in range(hi - lo)] + [ref["recs"][:0, 0]])
+packed = torch.zeros((max(1, (hi - lo) * recs.shape[1]), 64), dtype=torch.uint8)          # capacity, mostly unused
+packed[:len(rows)] = torch.from_numpy(rows.view(np.uint8).reshape(-1, 64).copy())
+pa, oa, totals = gather_packed(packed, offs, dst=0)
+if rank == 0:
+    assert totals == [int(whole["counts"][a:b].sum()) for a, b in (channel_range(r, world, C) for r in range(world))]
+    want_offs = np.concatenate([[0], np.cumsum(whole["counts"])]).astype(np.int32)
+    assert np.array_equal(oa.numpy(), want_offs) and pa.shape[0] == want_offs[-1]
+    for c in range(C):
+        assert pa[want_offs[c]:want_offs[c + 1]].numpy().tobytes() == whole["recs"][c, :whole["counts"][c]].tobytes()
+    print("PACKED_OK", pa.shape[0] * 64, "bytes of records against", gr.numel(), "unpacked")
 dist.destroy_process_group()
 """
 
@@ -104,7 +118,7 @@ def test_two_rank_scatter_gather_over_gloo(tmp_path):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert "GATHER_OK" in outs[0]
+    assert "GATHER_OK" in outs[0] and "PACKED_OK" in outs[0]
 
 
 def test_net_frame_format():

@@ -771,7 +771,7 @@ def test_net_frames_on_device_match_the_reference_sink():
     assert frames > Cn * 8, frames
     # the sink's capacity is part of the contract: a call whose rec_cap differs from it is refused before anything is
     # launched, by the Python mirror and by the C-ABI alike (the sink is indexed with the call's rec_cap)
-    small = rx.alloc_outputs(nblk - 2)
+    small = rx.alloc_outputs(nblk - 2, rec_cap=2 * (nblk - 2) + 2)
     assert small["rec_cap"] != net.shape[1]
     part = torch.from_numpy(np.ascontiguousarray(sig["iq"][:, :nblk - 2])).cuda()
     with pytest.raises(ValueError):
@@ -805,6 +805,44 @@ def test_parse_lsf_batch_matches_the_oracle():
     np.testing.assert_array_equal(got, want)
     assert want[:40 + n_built, 58].all() and not want[40 + n_built:, 58].all()   # crc_ok of sent / built LSFs; random ones fail
     assert bytes(got[40, 16:25]) == b"BROADCAST" and bytes(got[40, 26:35]) == b"G4GUO/P  "
+    rx.close()
+
+
+def test_pack_records_is_the_valid_rows_in_channel_order():
+    """m17gpu_pack_records (the compaction in front of the multi-GPU gather): offsets = exclusive scan of the counts,
+    packed = the valid rows, channel-major -- at a size that needs several scan tiles, with empty channels in it and
+    with a capacity overflow (counts above rec_cap are clamped like the record writer clamps them)."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    Cn, nblk = 2500, 6
+    rx = m.Receiver(Cn, nblk)
+    sig = rx.gen_batch(nblk, n_stream_frames=3)
+    iq = sig["iq"]
+    iq[::7] = 0                                            # squelched channels: no records at all
+    out = rx.rx_blocks(iq, 1, rx.alloc_outputs(nblk))
+    packed, offs = rx.pack_records(out)
+    torch.cuda.synchronize()
+    counts = out["counts"].cpu().numpy()
+    recs = out["recs"].cpu().numpy()
+    assert (counts[::7] == 0).all() and counts.sum() > Cn
+    want = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    np.testing.assert_array_equal(offs.cpu().numpy(), want)
+    rows = packed.cpu().numpy()[:want[-1]]
+    assert rows.tobytes() == b"".join(recs[c, :counts[c]].tobytes() for c in range(Cn))
+    ur, uc = rx.unpack_records(packed, offs, out["rec_cap"])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(uc.cpu().numpy(), counts)
+    ur = ur.cpu().numpy()
+    for c in range(0, Cn, 37):
+        assert ur[c, :counts[c]].tobytes() == recs[c, :counts[c]].tobytes() and not ur[c, counts[c]:].any()
+    # counts beyond the capacity (a caller-supplied array): clamped to rec_cap
+    big = out["counts"].clone()
+    big[5] = 1000
+    out2 = dict(out, counts=big)
+    _, offs2 = rx.pack_records(out2)
+    torch.cuda.synchronize()
+    cl = np.minimum(big.cpu().numpy(), out["rec_cap"])
+    np.testing.assert_array_equal(offs2.cpu().numpy(), np.concatenate([[0], np.cumsum(cl)]).astype(np.int32))
     rx.close()
 
 
