@@ -145,7 +145,7 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  *                            block, up to 1,024 channels; one wave per channel with scalar control and
  *                            the filter taps in SGPRs beyond; 7 = that kernel at every size
  *   "fe_impl"            0 = by size (default), 1 = lane per channel-block, 2 = four lanes per
- *                            channel-block
+ *                            channel-block, 3 = four lanes with the DC chain and the /5 pick in registers
  *   "fir_impl"           0 | 1 = front end and timing / framer as two kernels (default); 2 = the whole FIR stage
  *                            of a channel in one wave (k_rx_fused: no discriminator stream in HBM; measured slower,
  *                            DESIGN.md section 6)

@@ -489,6 +489,185 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
 }
 
 // ---------------------------------------------------------------------------
+// k_frontend_d: k_frontend_q with the DC sum and the /5 pick kept in registers (round 4).
+// k_frontend_q sends every u * 0.5 through LDS a second time -- four ds_write_b128 per lane and chunk (13 LDS-pipe
+// cycles each on gfx950 and, 16 dwords apart in a row of 68, two-way bank-conflicted) and sixteen ds_read_b128 by the
+// chain lane -- which made the CU's LDS pipe the busiest unit of the kernel (~0.22 of its 0.33 ms at 16,384 x 12: 44 %
+// of its LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT in profiles/r03_b_pmc_sq_full.txt).  Here the chain
+// walks the quad instead: in step s the lane with sub == s adds its sixteen values, in sample order, to the sum its
+// left neighbour finished in step s - 1 (quad_perm [0,0,1,2]; sub 0 starts from the row's sum so far).  Lanes whose
+// turn has not come compute on stale input and are overwritten when it comes; lanes whose turn has passed recompute
+// the same value from the same input.  Four steps of 1 + 1 + 16 instructions on all lanes replace 64 adds + 16 reads on a
+// quarter of them.  The picks (sample position % 5 == 4) are at most four of a lane's sixteen values: entries e0, e0+5,
+// e0+10 (and 15 when e0 == 0) with e0 = 4 - (lane's first position % 5), written straight into the output tile.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_quad_left(float v)       // quad lanes (0,1,2,3) read lanes (0,0,1,2)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x90, 0xF, 0xF, true));
+}
+__global__ __launch_bounds__(64 * FQ_WAVES, 4)
+void k_frontend_d(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
+                  float *__restrict__ disc_raw, float *__restrict__ offs,
+                  int nblk, int total, int update_state)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[FQ_WAVES][16 * FQ_STRIDE];  // raw IQ of one chunk
+    __shared__ __attribute__((aligned(16))) float otile[FQ_WAVES][16 * FQ_STRIDE];    // 64 picked outputs per row
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int cbl = lane >> 2, sub = lane & 3;
+    const int cb0 = ((int)blockIdx.x * FQ_WAVES + wave) * 16;
+    if (cb0 >= total) return;
+    const bool valid = (cb0 + cbl) < total;
+    const int cb = valid ? cb0 + cbl : total - 1;
+    const int chan = cb / nblk, blk = cb - chan * nblk;
+    uint32_t *my = tile[wave];
+    float *myo = otile[wave];
+
+    float c0re, c0im, c1re, c1im;
+    float n0re = 0.0f, n0im = 0.0f, n1re = 0.0f, n1im = 0.0f;
+    if (blk == 0) {
+        c0re = st[chan].z0re; c0im = st[chan].z0im; c1re = st[chan].z1re; c1im = st[chan].z1im;
+        fe_next_z(iq, cb, nblk, n0re, n0im, n1re, n1im);
+    } else {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(iq) + (size_t)cb * kBlockSamples;
+        const uint32_t a = p[-2], b = p[-1];
+        c1re = s16_to_float((int)(short)(a & 0xFFFF)); c1im = s16_to_float((int)a >> 16);
+        c0re = s16_to_float((int)(short)(b & 0xFFFF)); c0im = s16_to_float((int)b >> 16);
+        limit(c1re, c1im);
+        limit(c0re, c0im);
+    }
+
+    const int lr = lane >> 4, c16 = lane & 15;
+    auto row_ptr = [&](int j) {
+        int row = cb0 + j * 4 + lr; row = row < total ? row : total - 1;
+        return iq + (size_t)row * (kBlockSamples / 4) + c16;
+    };
+    const uint4 *g0 = row_ptr(0), *g1 = row_ptr(1), *g2 = row_ptr(2), *g3 = row_ptr(3);
+    const int l0 = lr * FQ_STRIDE + c16 * 4, l1 = l0 + 4 * FQ_STRIDE, l2 = l0 + 8 * FQ_STRIDE, l3 = l0 + 12 * FQ_STRIDE;
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    auto ld = [](const uint4 *p) {
+        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    uint4 s0 = ld(g0), s1 = ld(g1), s2 = ld(g2), s3 = ld(g3);
+
+    float offset = 0.0f;                                      // the row's DC sum so far, in all four lanes of the quad
+    float *dst = disc_raw + (size_t)cb * kDiscOut;
+    const bool sub0 = sub == 0;
+    float *orow = &myo[cbl * FQ_STRIDE];
+
+    auto chunk_body = [&](int chunk, auto c5tag) {
+        constexpr int C5 = decltype(c5tag)::value;
+        *reinterpret_cast<uint4 *>(&my[l0]) = s0;
+        *reinterpret_cast<uint4 *>(&my[l1]) = s1;
+        *reinterpret_cast<uint4 *>(&my[l2]) = s2;
+        *reinterpret_cast<uint4 *>(&my[l3]) = s3;
+        {
+            const int nx = ((chunk + 1 < FQ_NCHUNK) ? chunk + 1 : chunk) * (FQ_CHUNK / 4);
+            s0 = ld(g0 + nx); s1 = ld(g1 + nx); s2 = ld(g2 + nx); s3 = ld(g3 + nx);
+        }
+        wave_lds_sync();
+        uint32_t w[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&my[cbl * FQ_STRIDE + sub * 16 + q * 4]);
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+        wave_lds_sync();                                       // every lane holds its samples: the tile is free
+        // conversion + limiter on (re, im) pairs, the exact-arithmetic sequences of s16_to_float / sqrt_rn_normal /
+        // rcp_rn_normal written on two-vectors so that they issue as packed fp32 (same IEEE operations, same order):
+        // per sample pair the six fix-up operations of the limiter are three packed ones
+        v2f z[16];
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            v2f x0 = {(float)(int)(short)(w[e] & 0xFFFF), (float)((int)w[e] >> 16)};
+            v2f x1 = {(float)(int)(short)(w[e + 1] & 0xFFFF), (float)((int)w[e + 1] >> 16)};
+            const v2f chi = {0x1.f75104p-16f, 0x1.f75104p-16f}, clo = {0x1.aaa3aep-41f, 0x1.aaa3aep-41f};
+            x0 = __builtin_elementwise_fma(x0, chi, x0 * clo);            // s16_to_float
+            x1 = __builtin_elementwise_fma(x1, chi, x1 * clo);
+            const v2f q0 = x0 * x0, q1 = x1 * x1;
+            const v2f a = {q0.x + q0.y, q1.x + q1.y};                      // re * re + im * im of the two samples
+            const v2f q = {__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)};
+            const v2f y0 = a * q;                                          // sqrt_rn_normal
+            const v2f r = __builtin_elementwise_fma(-y0, y0, a);
+            const v2f m = __builtin_elementwise_fma(r, q * (v2f){0.5f, 0.5f}, y0);
+            const v2f r0 = {__builtin_amdgcn_rcpf(m.x), __builtin_amdgcn_rcpf(m.y)};
+            const v2f er = __builtin_elementwise_fma(-m, r0, (v2f){1.0f, 1.0f});     // rcp_rn_normal
+            const v2f g = __builtin_elementwise_fma(er, r0, r0);
+            z[e] = x0 * (v2f){g.x, g.x};
+            z[e + 1] = x1 * (v2f){g.y, g.y};
+        }
+        v2f p0 = {dpp_row_shr1(z[15].x), dpp_row_shr1(z[15].y)};          // sample -1 of this lane's run
+        v2f p1 = {dpp_row_shr1(z[14].x), dpp_row_shr1(z[14].y)};          // sample -2
+        if (sub0) { p0 = (v2f){c0re, c0im}; p1 = (v2f){c1re, c1im}; }
+        c0re = dpp_quad_b3(z[15].x); c0im = dpp_quad_b3(z[15].y);
+        c1re = dpp_quad_b3(z[14].x); c1im = dpp_quad_b3(z[14].y);
+        float u[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            // dsp_arctan_disc2 (m17_dsp.cpp:194-222): z0 = sample e-1, z1 = sample e-2;  u = (z0.re (im - z1.im) - z0.im (re - z1.re)) / 2
+            const v2f z0 = (e >= 1) ? z[e >= 1 ? e - 1 : 0] : p0;
+            const v2f z1 = (e >= 2) ? z[e >= 2 ? e - 2 : 0] : (e == 1 ? p0 : p1);
+            const v2f d = z[e] - z1;
+            const v2f pr = d * (v2f){z0.y, z0.x};                          // (aa, bb)
+            u[e] = (pr.y - pr.x) * 0.5f;
+        }
+        // ---- strictly sequential DC sum (m17_dsp.cpp:211) through the quad
+        float T = offset;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float left = dpp_quad_left(T);
+            T = sub0 ? offset : left;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) T = T + u[e];
+        }
+        offset = dpp_quad_b3(T);
+        // ---- count % 5 == 0 pick (m17_dsp.cpp:207-210): positions C5 * 64 + 16 sub + e of the 320-sample period
+        {
+            const int m = (C5 * 4 + sub) % 5;                  // (first position) % 5: 64 % 5 == 4, 16 % 5 == 1
+            const int e0 = 4 - m;                              // first pick of this lane's run
+            const int o0 = (C5 * 64 + 16 * sub) / 5;           // its output index within the period (position e0 is the one with % 5 == 4)
+            // selects as v_cndmask on lane masks (left to itself the compiler builds a five-way divergent switch)
+            const unsigned long long k0 = __builtin_amdgcn_ballot_w64(e0 == 0), k1 = __builtin_amdgcn_ballot_w64(e0 == 1),
+                                     k2 = __builtin_amdgcn_ballot_w64(e0 == 2), k3 = __builtin_amdgcn_ballot_w64(e0 == 3);
+            auto sel5 = [&](float a0, float a1, float a2, float a3, float a4) {
+                float r;
+                asm("v_cndmask_b32 %0, %5, %4, %9\n\tv_cndmask_b32 %0, %0, %3, %8\n\tv_cndmask_b32 %0, %0, %2, %7\n\tv_cndmask_b32 %0, %0, %1, %6"
+                    : "=&v"(r) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "s"(k0), "s"(k1), "s"(k2), "s"(k3));
+                return r;
+            };
+            const float v0 = sel5(u[0], u[1], u[2], u[3], u[4]), v1 = sel5(u[5], u[6], u[7], u[8], u[9]),
+                        v2 = sel5(u[10], u[11], u[12], u[13], u[14]);
+            orow[o0] = v0;
+            orow[o0 + 1] = v1;
+            orow[o0 + 2] = v2;
+            if (e0 == 0) orow[o0 + 3] = u[15];
+        }
+    };
+
+    for (int it = 0; it < FQ_NCHUNK / 5; ++it) {
+        chunk_body(it * 5 + 0, std::integral_constant<int, 0>{});
+        chunk_body(it * 5 + 1, std::integral_constant<int, 1>{});
+        chunk_body(it * 5 + 2, std::integral_constant<int, 2>{});
+        chunk_body(it * 5 + 3, std::integral_constant<int, 3>{});
+        chunk_body(it * 5 + 4, std::integral_constant<int, 4>{});
+        wave_lds_sync();
+        // 64 outputs per row: the quad stores its row's 256 bytes
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(&myo[cbl * FQ_STRIDE + q * 16 + sub * 4]);
+            if (valid) *reinterpret_cast<float4 *>(dst + it * 64 + q * 16 + sub * 4) = v;
+        }
+        wave_lds_sync();
+    }
+    if (sub0 && valid) {
+        offs[cb] = offset / (float)kBlockSamples;
+        if (update_state && blk == 0) {
+            st[chan].z0re = n0re; st[chan].z0im = n0im; st[chan].z1re = n1re; st[chan].z1im = n1im;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_frontend_afc: the front end of ONE block with the AFC branch taken (m17_dsp.cpp:468): dsp_nco_mixer
 // (:390-408) between conversion and limiter, radio_get_afc_delta / radio_afc (radio.cpp:196-208) around it.
 // AFC closes a loop through the whole chain -- the correction applied to block b comes from the DC estimate of

@@ -51,7 +51,8 @@ struct m17gpu_ctx {
     unsigned long long dst_override = 0;     // 48-bit destination callsign written into every net frame (0 = keep the LSF's)
     int afc = 0;                             // 1 = AFC on (radio_set_afc_on): block-sequential front end
     bool profiling = false;
-    int fe_impl = 0;                         // 0 = by size (four lanes per channel-block), 1 = lane per channel-block, 2 = four lanes
+    int fe_impl = 0;                         // 0 = by size (four lanes per channel-block), 1 = lane per channel-block, 2 = four lanes,
+                                             // 3 = four lanes, DC chain and picks in registers (k_frontend_d: a third of the LDS traffic, same time)
     int sync_impl = 0;                       // 0 | 6 = timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond (default);
                                              // 7 = wave per channel at every size
     int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
@@ -173,7 +174,10 @@ int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc,
     // measured on MI355X (scripts/exp_scale.py): the 4-lane kernel wins at 51,200 .. 196,608 channel-blocks,
     // so it is the default at every size; fe_impl 1 keeps the one-lane kernel selectable
     const bool quad = ctx->fe_impl != 1;
-    if (quad)
+    if (ctx->fe_impl == 3)
+        hipLaunchKernelGGL(k_frontend_d, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st,
+                           reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state);
+    else if (quad)
         hipLaunchKernelGGL(k_frontend_q, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state | (ctx->fe_debug << 1));
     else
@@ -246,7 +250,7 @@ int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_c
     int n_other = cdiv(tasks, 2);
     if (n_other > 512) n_other = 512;
     int grid = cdiv(tasks, 4);
-    if (grid > 256 * 5) grid = 256 * 5;
+    if (grid > 256 * 5) grid = 256 * 5;             // (four or three workgroups per CU: 0.177-0.180 -> 0.196-0.200 / 0.191 ms, round 4)
     hipLaunchKernelGGL(k_decode_lists, dim3(grid + n_other), dim3(256), 0, st, fsym, work, nwork, (int)slots, recs,
                        ctx->d_genc, ctx->d_gerr, kSlotFloats, n_other);
     HIPCHK(hipGetLastError());
@@ -462,7 +466,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
     auto bad = [&]() { return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: value out of range for ") + name); };
     if (!std::strcmp(name, "sync_impl")) { if (value != 0 && value != 6 && value != 7) return bad(); ctx->sync_impl = value; }
-    else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 2) return bad(); ctx->fe_impl = value; }
+    else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 3) return bad(); ctx->fe_impl = value; }
     else if (!std::strcmp(name, "fir_impl")) { if (value < 0 || value > 2) return bad(); ctx->fir_impl = value; }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
 #ifdef M17_STAMPS

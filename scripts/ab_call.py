@@ -1,30 +1,30 @@
-"""Whole-call time of option settings on one workload, same process / same box (HIP events around K calls):
-   python scripts/ab_call.py C nblk mode name=value[,name=value] [more settings ...]"""
-import sys, os, statistics, torch
+"""Same-box A/B of option sets by the duration of the WHOLE call (HIP events around m17gpu_rx_blocks):
+   python scripts/ab_call.py C nblk mode "name=v,name=v" "-" ..."""
+import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import m17_sdr_amd as m
 C, nblk, mode = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-settings = sys.argv[4:] or [""]
-T = 12
+sets = sys.argv[4:] or ["-"]
+T = 20
 gen = m.Receiver(C, nblk)
 big = gen.gen_batch(nblk * T)["iq"]
-slabs = big.view(C, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4).contiguous()
+slabs = torch.empty((T, C, nblk, 1920, 2), dtype=torch.int16, device=big.device)
+slabs.copy_(big.view(C, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4))
 del big
 gen.close()
-for rnd in range(2):
-    for st in settings:
-        rows = []
-        for rep in range(3):
-            rx = m.Receiver(C, nblk)
-            for kv in filter(None, st.split(",")):
-                k, v = kv.split("="); rx.set_option(k, int(v))
-            out = rx.alloc_outputs(nblk, want_syms=(mode == 0))
-            for k in range(2): rx.rx_blocks(slabs[k], mode, out)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for k in range(2, T): rx.rx_blocks(slabs[k], mode, out)
-            e1.record()
-            torch.cuda.synchronize()
-            rows.append(e0.elapsed_time(e1) / (T - 2)); rx.close()
-        print(f"{st or 'default':44s} C={C} nblk={nblk} mode={mode}  call {statistics.median(rows):.4f} ms  (min {min(rows):.4f})", flush=True)
+for rep in range(3):
+    for opt in sets:
+        rx = m.Receiver(C, nblk)
+        if opt != "-":
+            for kv in opt.split(","):
+                k, v = kv.split("=")
+                rx.set_option(k, int(v))
+        out = rx.alloc_outputs(nblk, want_syms=(mode == 0))
+        for k in range(4): rx.rx_blocks(slabs[k], mode, out)
+        torch.cuda.synchronize()
+        rx.set_profiling(True)
+        for k in range(4, T): rx.rx_blocks(slabs[k], mode, out)
+        torch.cuda.synchronize()
+        ms, call, n = rx.call_ms()
+        print(f"{opt:28s} C={C} nblk={nblk} mode={mode}  call {call:.4f} ms   stages " + " ".join(f"{x:.4f}" for x in ms), flush=True)
+        rx.close()

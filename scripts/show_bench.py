@@ -4,4 +4,5 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("step %.4f ms  value %.1f %s  frac %.4f  %s" % (d["ms_per_step"], d["value"], d["unit"], d["roofline"]["frac"], d["roofline"]["avg_ms"]))
 if d.get("noisy"): print("noisy", {k: d["noisy"][k] for k in d["noisy"] if k != "workload"})
 if d.get("fir_stage"): print("fir_stage frac %.4f  %s" % (d["fir_stage"]["frac"], d["fir_stage"]["avg_ms"]))
+if d.get("fir_stage_16384"): print("fir_stage_16384 frac %.4f  %s" % (d["fir_stage_16384"]["frac"], d["fir_stage_16384"]["avg_ms"]))
 if d.get("cpu_baseline"): print("cpu", d["cpu_baseline"])
