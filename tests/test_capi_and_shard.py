@@ -31,6 +31,41 @@ def test_library_exports_every_declared_symbol():
     assert C.sizeof(_lib.Rec) == 64
 
 
+def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
+    """The drop-in boundary is a C ABI: include/m17gpu.h must compile as C99 (no C++, no torch, no HIP or RCCL types) and a
+    C program must link against libm17gpu.so with nothing but that header -- here one that touches only host-side entries
+    (no compute call without a GPU)."""
+    hdr = os.path.join(ROOT, "include", "m17gpu.h")
+    subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-x", "c", hdr], check=True)
+    src = tmp_path / "host.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <string.h>
+#include "m17gpu.h"
+int main(void) {
+    int lo = -1, hi = -1;
+    m17gpu_shard_range(3, 8, 131072, &lo, &hi);
+    uint8_t lsf[30]; memset(lsf, 0, sizeof lsf);
+    m17gpu_lsf_fields f;
+    if (m17gpu_parse_lsf(lsf, &f) != M17GPU_OK) return 2;
+    m17gpu_ctx *ctx = NULL;
+    int rc = m17gpu_create(&ctx, 4, 2, 0);          /* no device here: must fail loudly, never fall back */
+    printf("%d %d %d %s\n", lo, hi, rc, f.dst_call);
+    if (rc == M17GPU_OK) m17gpu_destroy(ctx);
+    return 0;
+}
+""")
+    exe = tmp_path / "host"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", os.path.join(ROOT, "m17_sdr_amd"), "-lm17gpu", "-Wl,-rpath," + os.path.join(ROOT, "m17_sdr_amd"),
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert out[0] == "49152" and out[1] == "65536"
+    import torch
+    if not torch.cuda.is_available():
+        assert int(out[2]) == -1                       # M17GPU_ERR_NO_DEVICE
+
+
 def test_compat_shim_exports_reference_signatures():
     out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "m17_sdr_amd", "libm17compat.so")],
                          capture_output=True, text=True, check=True).stdout
