@@ -62,6 +62,8 @@ def parse_args(argv=None):
                          "entries of include/m17gpu.h on an ncclComm_t; given explicitly the legs also run at N=1 (degenerate: "
                          "device copies, every call made)")
     ap.add_argument("--no-syms", action="store_true", help="front end: do not write the symbol stream")
+    ap.add_argument("--no-settle", action="store_true",
+                    help="skip the untimed clock-settling calls in front of the warm-up steps (the timed region then sees the DVFS ramp)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="m17gpu_set_option on the receiver (A/B of bit-identical kernel variants; recorded in config)")
     args = ap.parse_args(argv)
@@ -229,6 +231,24 @@ def cpu_baseline(mode, sig):
             "realtime_channels": int(v * 1e6 / 4800)}
 
 
+def settle(torch, device, rx, slabs, mode, out, seconds=0.4):
+    """Untimed conditioning before the W warm-up steps: the same step, back to back over whole passes of the resident
+    stream, for about `seconds`.  The shader clock of an MI355X follows the load with a lag (scripts/exp_clock.py,
+    profiles/r04_clock_under_load.txt: 1.8 GHz in the first calls behind the signal generator's kernels, 2.25-2.37 GHz
+    after 200 back-to-back calls), so a region timed a few milliseconds after the generator would measure the ramp,
+    not the receiver.  Nothing of this is timed; the W warm-up steps and the K timed steps follow unchanged.  Returns the
+    number of calls made (a multiple of the number of distinct slabs: the stream stays continuous)."""
+    n = len(slabs)
+    t_end = time.perf_counter() + seconds
+    calls = 0
+    while time.perf_counter() < t_end and calls < 4000:
+        for k in range(n):
+            rx.rx_blocks(slabs[k], mode, out)
+        torch.cuda.synchronize(device)
+        calls += n
+    return calls
+
+
 def load_traffic(key):
     """HBM-side bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE doubled, WRITE_SIZE as is:
     MI355X_MICROARCH.md, HBM section).  Measured offline with rocprofv3 --pmc (it cannot run inside this process);
@@ -276,6 +296,7 @@ def fir_stage(args, torch, device, C=1024, nblk=50, steps=30, warm=3):
     slabs.copy_(big.view(C, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4))
     del big
     out = rx.alloc_outputs(nblk, want_syms=True)
+    settled = settle(torch, device, rx, slabs, 0, out)
     for k in range(warm):
         rx.rx_blocks(slabs[k], 0, out)
     torch.cuda.synchronize(device)
@@ -296,7 +317,7 @@ def fir_stage(args, torch, device, C=1024, nblk=50, steps=30, warm=3):
             "ms": round(dt / steps * 1e3, 4), "value": round(C * nblk * 192 * steps / dt / 1e6, 3), "unit": "Msym/s",
             "frac": ro["frac"], "achieved": ro["achieved"], "traffic": ro["traffic"], "avg_ms": ro["avg_ms"],
             "kernel_sum_ms": ro["kernel_sum_ms"], "algorithmic_bytes_per_channel_block": BYTES_FRONT,
-            "channel_blocks_per_launch": C * nblk, "steps": steps, "target_frac": 0.40}
+            "channel_blocks_per_launch": C * nblk, "steps": steps, "warmup": warm, "settle_calls": settled, "target_frac": 0.40}
 
 
 def noisy_leg(args, torch, device, C, nblk, ebn0=8.0):
@@ -316,6 +337,7 @@ def noisy_leg(args, torch, device, C, nblk, ebn0=8.0):
     slabs.copy_(big.view(C, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4))
     del big
     out = rx.alloc_outputs(nblk)
+    settled = settle(torch, device, rx, slabs, 1, out)
     for k in range(warm):
         rx.rx_blocks(slabs[k], 1, out)
     torch.cuda.synchronize(device)
@@ -335,7 +357,8 @@ def noisy_leg(args, torch, device, C, nblk, ebn0=8.0):
     return {"workload": f"full chain, {C:,} channels x {nblk} blocks, band-limited AWGN at Eb/N0 {ebn0:g} dB (BASELINE configs[3])",
             "ebn0_db": ebn0, "ms": round(dt / steps * 1e3, 4), "value": round(C * nblk * 192 * steps / dt / 1e6, 3),
             "unit": "Msym/s", "frac": ro["frac"], "achieved": ro["achieved"], "avg_ms": ro["avg_ms"],
-            "kernel_sum_ms": ro["kernel_sum_ms"], "steps": steps, "channels_locked_at_end": locked}
+            "kernel_sum_ms": ro["kernel_sum_ms"], "steps": steps, "warmup": warm, "settle_calls": settled,
+            "channels_locked_at_end": locked}
 
 
 def host_cores():
@@ -587,6 +610,9 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    settled = 0
+    if not args.no_settle:
+        settled = settle(torch, local, rx, iq[:Tg], mode, out)
     for k in range(args.warmup):
         rx.rx_blocks(iq[k], mode, out)
     barrier()
@@ -620,6 +646,9 @@ def run_rank(args):
                    "channels_per_gpu": C, "channels_total": world * C, "blocks_per_step": nblk, "samples_per_block": 1920,
                    "realtime_channels": int(msym * 1e6 / 4800), "realtime_channels_per_gpu": int(msym * 1e6 / 4800 / world),
                    "ebn0_db": args.ebn0,
+                   "settle_calls": settled,
+                   "settle_note": "untimed conditioning in front of the warm-up steps: the same step back to back for ~0.4 s, so that the "
+                                  "shader clock has followed the load (DESIGN.md section 6; --no-settle to measure the ramp instead)",
                    "signal_source": ("m17gpu_gen_batch (device), one continuous stream per channel, %d distinct steps "
                                      "(%.1f s) cut into %d-block steps%s" % (Tg, 0.04 * nblk * Tg, nblk, ", wrapping" if Tg < T else "")
                                      if args.gen == "gpu" else "m17gen_batch (host, tiled), the same slab every step"),

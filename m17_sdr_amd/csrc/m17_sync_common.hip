@@ -83,6 +83,8 @@ __device__ __forceinline__ void store_frame_slot(float *__restrict__ fd, int typ
 #ifdef M17_STAMPS
 __device__ unsigned long long g_stamps[16];
 __device__ unsigned long long g_chan_stamps[4096][8];      // per channel: the phase accumulators of its wave
+__device__ unsigned long long g_chan_stamps_x[4096][2];    // ... and its epilogue
+__device__ unsigned long long g_wave_span[16384][3];       // per channel: s_memrealtime at entry / exit (100 MHz, one clock for the chip), HW_ID
 #define DBGCNT(i) do { if (t == 0) atomicAdd(&g_stamps[12 + (i)], 1ull); } while (0)
 #define STAMP(i) do { unsigned long long now_; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \

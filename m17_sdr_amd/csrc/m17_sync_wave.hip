@@ -333,6 +333,10 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
 {
     constexpr int LPC = 64;
     __shared__ __attribute__((aligned(4096))) WvChan chs[WV_WAVES];
+#ifdef M17_STAMPS
+    const unsigned t_entry_ = (unsigned)__builtin_amdgcn_s_memtime();
+    const unsigned long long rt_entry_ = __builtin_amdgcn_s_memrealtime();
+#endif
     const int wave = uni((int)(threadIdx.x >> 6)), gl = lane_id();
     const int chan = (int)blockIdx.x * WV_WAVES + wave;
     if (chan >= C) return;
@@ -375,6 +379,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
     if (gl < 12) wstamps[wave][gl] = 0;
     wst = wstamps[wave];
     t.last_ = (unsigned)__builtin_amdgcn_s_memtime();
+    if (gl == 0) wstamps[wave][6] = t.last_ - t_entry_;       // prologue: state and first block in
 #endif
     for (int b = b0; b < bend; ++b) {
         WSTAMP(5);
@@ -410,11 +415,27 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
 
 #ifdef M17_STAMPS
     WSTAMP(5);
-    if (chan < 4096 && gl < 8) g_chan_stamps[chan][gl] = wstamps[wave][gl < 7 ? gl : 8];
 #endif
     // ---- store state in the reference's layout
     wv_store_state(t, cs, counts, chan, ext_lock, hb, gl);
     if (gl < kTaps - 1) cs.buff[gl + 1] = my.x[gl];
+#ifdef M17_STAMPS
+    // epilogue (state out, every store of the wave complete: what s_endpgm waits for), the wave's life on the chip-wide
+    // 100 MHz clock and in s_memtime ticks (scripts/exp_stamps_wave.py, scripts/exp_clock.py)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime();
+        if (gl == 0) wstamps[wave][9] = now_ - t.last_;
+    }
+    wave_fence();
+    if (chan < 4096 && gl < 8) g_chan_stamps[chan][gl] = wstamps[wave][gl < 7 ? gl : 8];
+    if (chan < 4096 && gl == 0) g_chan_stamps_x[chan][0] = wstamps[wave][9];
+    if (chan < 16384 && gl == 0) {
+        g_wave_span[chan][0] = rt_entry_; g_wave_span[chan][1] = __builtin_amdgcn_s_memrealtime();
+        g_wave_span[chan][2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11)) |
+                               ((unsigned long long)((unsigned)__builtin_amdgcn_s_memtime() - t_entry_) << 32);
+    }
+#endif
 }
 
 } // namespace m17dev

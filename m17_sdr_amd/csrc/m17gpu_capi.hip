@@ -427,6 +427,18 @@ int m17gpu_debug_fe_span(unsigned long long *out /* [16384][2] */)
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fe_span), sizeof(unsigned long long) * 16384 * 2));
     return 0;
 }
+int m17gpu_debug_wave_span(unsigned long long *out /* [16384][3] */)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_span), sizeof(unsigned long long) * 16384 * 3));
+    return 0;
+}
+int m17gpu_debug_chan_stamps_x(unsigned long long *out /* [4096][2] */)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chan_stamps_x), sizeof(unsigned long long) * 4096 * 2));
+    return 0;
+}
 int m17gpu_debug_chan_stamps(unsigned long long *out /* [4096][8] */)
 {
     HIPCHK(hipDeviceSynchronize());
