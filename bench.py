@@ -657,41 +657,49 @@ def run_rank(args):
     }
     if args.option:
         line["config"]["options"] = list(args.option)
-    fan = None
     if (world > 1 or args.fanout) and not args.no_fanout:
         # After the timed region and outside `value`: neither a failure nor a HANG of the transfer legs may cost the
         # measurement.  A collective that never returns cannot be cancelled, so a watchdog prints the line as it stands
-        # (rank 0) and ends the process on every rank when the legs overrun their allowance.
+        # (rank 0) -- with whatever legs have finished -- and ends the process on every rank when a set of legs overruns
+        # its allowance.  N > 1 without --fanout runs BOTH bindings one after the other: the torch.distributed one
+        # (rehearsed over gloo with two ranks) first, then the C-ABI entries on their own communicator (rehearsed with
+        # one rank only: no multi-GPU box so far), so that a node that has the GPUs exercises both.
         import threading
         allowance = float(os.environ.get("M17_BENCH_FANOUT_TIMEOUT", "120"))
+        transports = [args.fanout] if args.fanout else (["torch", "capi"] if backend == "nccl" else ["torch"])
+        current = ["fanout"]
 
         def overrun():
             if rank == 0:
-                line["fanout"] = {"fanout_error": f"the transfer legs did not finish within {allowance:g} s; abandoned"}
+                line[current[0]] = {"fanout_error": f"the transfer legs did not finish within {allowance:g} s; abandoned"}
                 line["cpu_baseline"] = None
                 sys.stdout.write(json.dumps(line) + "\n")
                 sys.stdout.flush()
             os._exit(0)
 
-        dog = threading.Timer(allowance, overrun)
-        dog.daemon = True
-        dog.start()
-        try:
-            fan = fanout_legs(args, torch, dist, rx, out, iq[args.warmup % len(iq)], world, rank, backend, C, nblk, mode)
-        except Exception as e:                                   # noqa: BLE001 -- a dead peer, a failed barrier: reported, the line survives
-            fan = {"fanout_error": f"{type(e).__name__}: {e}"[:300]}
-        dog.cancel()
-    if fan is not None:
-        line["fanout"] = fan
-    if fan is not None and "fanout_ms" in fan:
-        wf = ms_step + fan["fanout_ms"] + fan["gather_ms"]
-        line["with_fanout"] = {"ms_per_step": round(wf, 4), "value": round(world * C * nblk * 192 / (wf * 1e-3) / 1e6, 3),
-                               "unit": "Msym/s", "note": "compute step + scatter of the IQ from rank 0 + gather of the packed records, one after the other"}
-        if fan.get("overlapped_ms_per_step"):
-            wo = fan["overlapped_ms_per_step"]
-            line["with_fanout_overlapped"] = {"ms_per_step": round(wo, 4), "value": round(world * C * nblk * 192 / (wo * 1e-3) / 1e6, 3),
-                                              "unit": "Msym/s", "note": "double-buffered: the scatter of step k+1 on a second stream beside "
-                                                                         "the compute and the packed gather of step k"}
+        for ti, tr in enumerate(transports):
+            key = "fanout" if ti == 0 else f"fanout_{tr}"
+            current[0] = key
+            dog = threading.Timer(allowance, overrun)
+            dog.daemon = True
+            dog.start()
+            args.fanout = tr
+            try:
+                fan = fanout_legs(args, torch, dist, rx, out, iq[args.warmup % len(iq)], world, rank, backend, C, nblk, mode)
+            except Exception as e:                               # noqa: BLE001 -- a dead peer, a failed barrier: reported, the line survives
+                fan = {"fanout_error": f"{type(e).__name__}: {e}"[:300]}
+            dog.cancel()
+            line[key] = fan
+            sfx = "" if ti == 0 else f"_{tr}"
+            if "fanout_ms" in fan:
+                wf = ms_step + fan["fanout_ms"] + fan["gather_ms"]
+                line["with_fanout" + sfx] = {"ms_per_step": round(wf, 4), "value": round(world * C * nblk * 192 / (wf * 1e-3) / 1e6, 3),
+                                             "unit": "Msym/s", "note": "compute step + scatter of the IQ from rank 0 + gather of the packed records, one after the other"}
+                if fan.get("overlapped_ms_per_step"):
+                    wo = fan["overlapped_ms_per_step"]
+                    line["with_fanout_overlapped" + sfx] = {"ms_per_step": round(wo, 4), "value": round(world * C * nblk * 192 / (wo * 1e-3) / 1e6, 3),
+                                                            "unit": "Msym/s", "note": "double-buffered: the scatter of step k+1 on a second stream beside "
+                                                                                       "the compute and the packed gather of step k"}
     if rank == 0:
         rx.close()
         del iq
