@@ -109,7 +109,7 @@ from m17_sdr_amd.shard import channel_range, gather_packed, gather_records, scat
 from tests import oracle
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-C, nblk = 7, 10
+C, nblk = int(os.environ.get("M17_TEST_CHANNELS", "7")), 10
 full = None
 if rank == 0:
     full = torch.from_numpy(m.generate_batch(C, nblk, n_stream_frames=4)["iq"])
@@ -118,7 +118,7 @@ lo, hi = channel_range(rank, world, C)
 assert mine.shape[0] == hi - lo
 # the oracle stands in for the per-GPU receive chain in this CPU test
 ref = oracle.Channels(hi - lo).rx_blocks(mine.numpy().copy(), mode=1)
-recs = torch.from_numpy(ref["recs"].view(np.uint8).reshape(hi - lo, -1, 64).copy())
+recs = torch.from_numpy(ref["recs"].view(np.uint8).reshape(hi - lo, ref["recs"].shape[1], 64).copy())
 counts = torch.from_numpy(ref["counts"].copy())
 gr, gc = gather_records(recs, counts, dst=0)
 if rank == 0:
@@ -144,13 +144,17 @@ dist.destroy_process_group()
 """
 
 
-def test_two_rank_scatter_gather_over_gloo(tmp_path):
+@pytest.mark.parametrize("world,channels,port", [(2, 7, 29517), (3, 5, 29518), (3, 2, 29519)])
+def test_scatter_gather_over_gloo(tmp_path, world, channels, port):
+    """The N > 1 exchanges on the CPU: scatter of the IQ, gather of the records -- unpacked and packed -- at world sizes 2 and
+    3, with uneven channel ranges and (2 channels over 3 ranks) a rank that owns nothing; the gathered whole must equal the
+    oracle run on all channels at once."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, M17_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE="2",
-               OMP_NUM_THREADS="2")
+    env = dict(os.environ, M17_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+               OMP_NUM_THREADS="2", M17_TEST_CHANNELS=str(channels))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0] and "PACKED_OK" in outs[0]
