@@ -505,22 +505,17 @@ __device__ __forceinline__ float dpp_quad_left(float v)       // quad lanes (0,1
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x90, 0xF, 0xF, true));
 }
-__global__ __launch_bounds__(64 * FQ_WAVES, 4)
-void k_frontend_d(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
-                  float *__restrict__ disc_raw, float *__restrict__ offs,
-                  int nblk, int total, int update_state)
+// one tile = the 16 (channel, block) rows cb0 .. cb0 + 15; my / myo: the wave's raw and output tiles in LDS (16 x FQ_STRIDE dwords each)
+__device__ __forceinline__ void frontend_d_tile(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
+                                                float *__restrict__ disc_raw, float *__restrict__ offs,
+                                                int nblk, int total, int update_state, const int cb0, uint32_t *my, float *myo)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[FQ_WAVES][16 * FQ_STRIDE];  // raw IQ of one chunk
-    __shared__ __attribute__((aligned(16))) float otile[FQ_WAVES][16 * FQ_STRIDE];    // 64 picked outputs per row
-    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const int lane = lane_id();
     const int cbl = lane >> 2, sub = lane & 3;
-    const int cb0 = ((int)blockIdx.x * FQ_WAVES + wave) * 16;
     if (cb0 >= total) return;
     const bool valid = (cb0 + cbl) < total;
     const int cb = valid ? cb0 + cbl : total - 1;
     const int chan = cb / nblk, blk = cb - chan * nblk;
-    uint32_t *my = tile[wave];
-    float *myo = otile[wave];
 
     float c0re, c0im, c1re, c1im;
     float n0re = 0.0f, n0im = 0.0f, n1re = 0.0f, n1im = 0.0f;
@@ -665,6 +660,16 @@ void k_frontend_d(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
             st[chan].z0re = n0re; st[chan].z0im = n0im; st[chan].z1re = n1re; st[chan].z1im = n1im;
         }
     }
+}
+__global__ __launch_bounds__(64 * FQ_WAVES, 4)
+void k_frontend_d(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
+                  float *__restrict__ disc_raw, float *__restrict__ offs,
+                  int nblk, int total, int update_state)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[FQ_WAVES][16 * FQ_STRIDE];  // raw IQ of one chunk
+    __shared__ __attribute__((aligned(16))) float otile[FQ_WAVES][16 * FQ_STRIDE];    // 64 picked outputs per row
+    const int wave = (int)(threadIdx.x >> 6);
+    frontend_d_tile(iq, st, disc_raw, offs, nblk, total, update_state, ((int)blockIdx.x * FQ_WAVES + wave) * 16, tile[wave], otile[wave]);
 }
 
 // ---------------------------------------------------------------------------

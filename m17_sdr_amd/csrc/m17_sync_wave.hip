@@ -321,26 +321,21 @@ __device__ __forceinline__ void wv_store_state(const WvCtl &t, ChanState &cs, in
     }
 }
 
-// (six waves per SIMD: a seventh -- 72 VGPRs, amdgpu_waves_per_eu(7, 7), 16 B of scratch -- changes nothing, 0.294-0.303 against
-//  0.302 ms on one box, round 4; eight with 14 VGPRs in scratch are slower, round 3)
-__global__ __launch_bounds__(64 * WV_WAVES, 6)
-void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
-                       const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
+// the whole call of ONE channel by the calling wave; `my` = the channel's 4 KB of LDS (4 KB-aligned), wave = the wave's
+// index in its workgroup (instrumented build only)
+__device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc, const float *__restrict__ offs,
                        ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
                        m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
                        float *__restrict__ syms, int32_t *__restrict__ nsyms,
-                       float *__restrict__ fsym, int b0, int bcount)
+                       float *__restrict__ fsym, int b0, int bcount, const int chan, WvChan &my, const int wave)
 {
     constexpr int LPC = 64;
-    __shared__ __attribute__((aligned(4096))) WvChan chs[WV_WAVES];
 #ifdef M17_STAMPS
     const unsigned t_entry_ = (unsigned)__builtin_amdgcn_s_memtime();
     const unsigned long long rt_entry_ = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int wave = uni((int)(threadIdx.x >> 6)), gl = lane_id();
-    const int chan = (int)blockIdx.x * WV_WAVES + wave;
+    const int gl = lane_id();
     if (chan >= C) return;
-    WvChan &my = chs[wave];
     const unsigned hb = (unsigned)uni((int)(unsigned)(uintptr_t)(lds_cfp)my.H);       // LDS byte address of the ring
     ChanState &cs = st[chan];
     if (!recs) rec_cap = 0;
@@ -375,7 +370,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
     unsigned *wst = nullptr;
 #ifdef M17_STAMPS
     // phase accumulators in LDS (the scalar registers are spoken for): lane 0 adds the ticks since the last stamp
-    __shared__ unsigned wstamps[WV_WAVES][12];
+    __shared__ unsigned wstamps[16][12];
     if (gl < 12) wstamps[wave][gl] = 0;
     wst = wstamps[wave];
     t.last_ = (unsigned)__builtin_amdgcn_s_memtime();
@@ -436,6 +431,49 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                                ((unsigned long long)((unsigned)__builtin_amdgcn_s_memtime() - t_entry_) << 32);
     }
 #endif
+}
+
+// (six waves per SIMD: a seventh -- 72 VGPRs, amdgpu_waves_per_eu(7, 7), 16 B of scratch -- changes nothing, 0.294-0.303 against
+//  0.302 ms on one box, round 4; eight with 14 VGPRs in scratch are slower, round 3)
+__global__ __launch_bounds__(64 * WV_WAVES, 6)
+void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
+                       const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
+                       ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
+                       m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
+                       float *__restrict__ syms, int32_t *__restrict__ nsyms,
+                       float *__restrict__ fsym, int b0, int bcount)
+{
+    __shared__ __attribute__((aligned(4096))) WvChan chs[WV_WAVES];
+    const int wave = uni((int)(threadIdx.x >> 6));
+    sync_wave_channel(disc, offs, st, C, nblk, mode, ext_lock, recs, rec_cap, counts, syms, nsyms, fsym, b0, bcount,
+                      (int)blockIdx.x * WV_WAVES + wave, chs[wave], wave);
+}
+
+// EXPERIMENT (round 4, profiles/r04_pc_mock.txt): what a producer / consumer workgroup could reach at best -- twelve
+// waves run the timing kernel's whole call for twelve channels, four run the front end's tiles for the same number of
+// channel-blocks, with no hand-over between them (each role reads and writes HBM as its stand-alone kernel does): the
+// same work as the two kernels of a step, co-resident at the register count of the larger role.
+constexpr int PC_CONS = 12, PC_PROD = 4;
+__global__ __launch_bounds__(64 * (PC_CONS + PC_PROD), 4)
+void k_pc_mock(const uint4 *__restrict__ iq, float *__restrict__ disc_w, float *__restrict__ offs_w,
+               const float *__restrict__ disc, const float *__restrict__ offs,
+               ChanState *__restrict__ st, ChanState *__restrict__ st_fe, int C, int nblk,
+               float *__restrict__ syms, int32_t *__restrict__ nsyms, float *__restrict__ fsym, int32_t *__restrict__ counts)
+{
+    __shared__ __attribute__((aligned(4096))) WvChan chs[PC_CONS];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[PC_PROD][16 * FQ_STRIDE];
+    __shared__ __attribute__((aligned(16))) float otile[PC_PROD][16 * FQ_STRIDE];
+    const int wave = uni((int)(threadIdx.x >> 6));
+    if (wave < PC_CONS) {
+        sync_wave_channel(disc, offs, st, C, nblk, 0, -1, nullptr, 0, counts, syms, nsyms, fsym, 0, nblk,
+                          (int)blockIdx.x * PC_CONS + wave, chs[wave], wave);
+    } else {
+        // this workgroup's share of the front end: PC_CONS channels x nblk blocks = PC_CONS * nblk / 16 tiles, dealt to the producers in turn
+        const int p = wave - PC_CONS, total = C * nblk;
+        const int tiles_per_wg = (PC_CONS * nblk + 15) / 16;
+        for (int k = p; k < tiles_per_wg; k += PC_PROD)
+            frontend_d_tile(iq, st_fe, disc_w, offs_w, nblk, total, 0, ((int)blockIdx.x * tiles_per_wg + k) * 16, tile[p], otile[p]);
+    }
 }
 
 } // namespace m17dev

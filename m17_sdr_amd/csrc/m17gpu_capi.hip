@@ -408,6 +408,20 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
     return M17GPU_OK;
 }
 
+// EXPERIMENT (not in the header): k_pc_mock on the context's discriminator stream -- call m17gpu_rx_blocks(mode 0) on the
+// same d_iq first, so that the producers rewrite what is already there.  One launch = the front end's and the timing
+// kernel's work of one step, co-resident.
+int m17gpu_debug_pc_mock(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *d_syms, int32_t *d_nsyms, void *stream)
+{
+    if (!ctx || !d_iq || nblk <= 0 || nblk > ctx->max_blocks) return fail(M17GPU_ERR_ARG, "m17gpu_debug_pc_mock: bad argument");
+    ON_CTX_DEVICE(ctx);
+    hipLaunchKernelGGL(k_pc_mock, dim3(cdiv(ctx->C, PC_CONS)), dim3(64 * (PC_CONS + PC_PROD)), 0, S(stream),
+                       reinterpret_cast<const uint4 *>(d_iq), ctx->d_disc, ctx->d_offs, ctx->d_disc, ctx->d_offs,
+                       ctx->d_state, ctx->d_state, ctx->C, nblk, d_syms, d_nsyms, ctx->d_fsym, ctx->d_counts);
+    HIPCHK(hipGetLastError());
+    return M17GPU_OK;
+}
+
 #ifdef M17_STAMPS
 int m17gpu_debug_stamps(unsigned long long *out)
 {
