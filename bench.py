@@ -390,23 +390,30 @@ class CapiFanout:
     ncclCommInitRank -- what a C++ host does with its own bootstrap."""
 
     def __init__(self, torch, dist, rx, world, rank, dev):
+        """Phase 1, local to this rank: load RCCL, rank 0 makes the unique id.  Nothing here can block on a peer, so a
+        failure (no librccl next to torch, ...) can be agreed on before any rank enters ncclCommInitRank (join)."""
         import ctypes as C
         import m17_sdr_amd as m
-        self.C, self.torch, self.rx, self.world, self.rank, self.lib = C, torch, rx, world, rank, m.lib()
+        self.C, self.torch, self.dist, self.rx, self.world, self.rank, self.dev = C, torch, dist, rx, world, rank, dev
+        self.lib, self.comm = m.lib(), None
         self.rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
 
         class UID(C.Structure):
             _fields_ = [("internal", C.c_char * 128)]
-        uid = UID()
-        if rank == 0 and self.rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+        self.UID, self.uid = UID, UID()
+        if rank == 0 and self.rccl.ncclGetUniqueId(C.byref(self.uid)) != 0:
             raise RuntimeError("ncclGetUniqueId failed")
-        if world > 1:
-            t = torch.frombuffer(bytearray(bytes(uid.internal) if rank == 0 else bytes(128)), dtype=torch.uint8).to(dev)
-            dist.broadcast(t, src=0)
-            C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+
+    def join(self):
+        """Phase 2, collective: the id travels over the process group, every rank joins the communicator."""
+        C, torch = self.C, self.torch
+        if self.world > 1:
+            t = torch.frombuffer(bytearray(bytes(self.uid.internal) if self.rank == 0 else bytes(128)), dtype=torch.uint8).to(self.dev)
+            self.dist.broadcast(t, src=0)
+            C.memmove(C.byref(self.uid), bytes(t.cpu().numpy().tobytes()), 128)
         self.comm = C.c_void_p()
-        self.rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
-        if self.rccl.ncclCommInitRank(C.byref(self.comm), world, uid, rank) != 0:
+        self.rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, self.UID, C.c_int]
+        if self.rccl.ncclCommInitRank(C.byref(self.comm), self.world, self.uid, self.rank) != 0:
             raise RuntimeError("ncclCommInitRank failed")
 
     def _chk(self, rc, what):
@@ -483,6 +490,13 @@ def fanout_legs(args, torch, dist, rx, out, iq_step, world, rank, backend, C, nb
         err = f"fan-out set-up on rank {rank}: {type(e).__name__}: {e}"[:300]
     if not all_ok(err):
         return {"fanout_error": err or "fan-out set-up failed on another rank"}
+    if capi:
+        try:
+            capi.join()                                          # collective: every rank got here (agreed above)
+        except Exception as e:                                   # noqa: BLE001
+            err = f"communicator on rank {rank}: {type(e).__name__}: {e}"[:300]
+        if not all_ok(err):
+            return {"fanout_error": err or "ncclCommInitRank failed on another rank"}
 
     main = torch.cuda.current_stream(dev)
     cap = int(out["rec_cap"])
