@@ -66,6 +66,13 @@ int main(void) {
         assert int(out[2]) == -1                       # M17GPU_ERR_NO_DEVICE
 
 
+def test_integration_host_loop_compiles():
+    """The C++ host loop INTEGRATION.md section B.2 describes (scatter, step, pack, packed gather, double-buffered) is kept as
+    tests/compat/host_loop_8gpu.cpp and must compile against include/m17gpu.h alone."""
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "compat", "host_loop_8gpu.cpp")], check=True)
+
+
 def test_compat_shim_exports_reference_signatures():
     out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "m17_sdr_amd", "libm17compat.so")],
                          capture_output=True, text=True, check=True).stdout
