@@ -213,16 +213,19 @@ def test_config2_1024_channels_front_end_bit_exact():
     _rx_compare(C=1024, nblk=10, mode=0, ebn0=7.0, nsf=6)
 
 
-@pytest.mark.parametrize("ebn0", [4.0, 8.0, 12.0])
-def test_config4_16384_channels_awgn_bit_exact(ebn0):
+@pytest.mark.parametrize("ebn0,options", [(4.0, {}), (8.0, {}), (12.0, {}), (10.0, {"fir_impl": 2}), (10.0, {"fe_impl": 3})])
+def test_config4_16384_channels_awgn_bit_exact(ebn0, options):
     """BASELINE configs[3] at its real size: 16,384 channels on one GPU, band-limited AWGN, signal from
     the device generator (every channel distinct), DEFAULT options -- so the kernels the bench runs at this size
-     run here at that size.  EVERY channel's symbols, symbol counts, records and end state
+     run here at that size -- and, at one Eb/N0 each, the fused FIR-stage kernel and the
+    register-chain front end at that size.  EVERY channel's symbols, symbol counts, records and end state
     are compared with the oracle (m17_rx_sync.cpp:77-99, m17_rx_frame.cpp:126-177 and the decode chain)."""
     torch = _torch()
     import m17_sdr_amd as m
     C, nblk = 16384, 12
     rx = m.Receiver(C, nblk)
+    for k, v in options.items():
+        rx.set_option(k, v)
     sig = rx.gen_batch(nblk, n_stream_frames=6, ebn0_db=ebn0, noise_cutoff_hz=6250.0)
     out = rx.rx_blocks(sig["iq"], 1, rx.alloc_outputs(nblk, want_syms=True))
     torch.cuda.synchronize()
