@@ -49,6 +49,9 @@ def parse_args(argv=None):
     ap.add_argument("--blocks", type=int, default=None, help="1920-sample blocks per channel per step (default 12 full / 50 frontend)")
     ap.add_argument("--workload", choices=["frontend", "full"], default="full")
     ap.add_argument("--ebn0", type=float, default=200.0, help="AWGN level of the synthetic IQ (>=100: none)")
+    ap.add_argument("--noise-cutoff", type=float, default=0.0,
+                    help="one-sided cutoff (Hz) of the channel filter on the AWGN of the device generator (0 = white over 48 kHz); "
+                         "--ebn0 8 --noise-cutoff 6250 is the workload of the nested `noisy` leg")
     ap.add_argument("--unique", type=int, default=256, help="host generator: distinct generated channels (tiled to --channels)")
     ap.add_argument("--gen", choices=["gpu", "host"], default="gpu",
                     help="signal source: m17gpu_gen_batch on the device (every channel distinct) or the host generator")
@@ -142,7 +145,8 @@ def make_input(args, rank, torch, rx, C, nblk, T):
         Tg = max(1, min(T, int(args.signal_gb * 1e9 // (C * nblk * 7680))))
         # the generator writes one stream per channel [C][nblk*Tg]; the C-ABI takes [C][nblk] per step, so the
         # stream is re-laid out once as [step][C][nblk] (peak 2 x the signal; 288 GB of HBM make that a non-issue)
-        big = rx.gen_batch(nblk * Tg, n_stream_frames=40, ebn0_db=args.ebn0, first_channel=rank * C)["iq"]
+        big = rx.gen_batch(nblk * Tg, n_stream_frames=40, ebn0_db=args.ebn0, first_channel=rank * C,
+                           noise_cutoff_hz=args.noise_cutoff)["iq"]
         torch.cuda.synchronize(rx.device)
         slabs = torch.empty((Tg, C, nblk, 1920, 2), dtype=torch.int16, device=big.device)
         slabs.copy_(big.view(C, Tg, nblk, 1920, 2).permute(1, 0, 2, 3, 4))
@@ -356,7 +360,7 @@ def noisy_leg(args, torch, device, C, nblk, ebn0=8.0):
     ro = roofline_obj(kms, ncalls, 1, C * nblk, f"full-noisy:{C}x{nblk}")
     return {"workload": f"full chain, {C:,} channels x {nblk} blocks, band-limited AWGN at Eb/N0 {ebn0:g} dB (BASELINE configs[3])",
             "ebn0_db": ebn0, "ms": round(dt / steps * 1e3, 4), "value": round(C * nblk * 192 * steps / dt / 1e6, 3),
-            "unit": "Msym/s", "frac": ro["frac"], "achieved": ro["achieved"], "avg_ms": ro["avg_ms"],
+            "unit": "Msym/s", "frac": ro["frac"], "achieved": ro["achieved"], "traffic": ro["traffic"], "avg_ms": ro["avg_ms"],
             "kernel_sum_ms": ro["kernel_sum_ms"], "steps": steps, "warmup": warm, "settle_calls": settled,
             "channels_locked_at_end": locked}
 
@@ -667,7 +671,8 @@ def run_rank(args):
                                      "(%.1f s) cut into %d-block steps%s" % (Tg, 0.04 * nblk * Tg, nblk, ", wrapping" if Tg < T else "")
                                      if args.gen == "gpu" else "m17gen_batch (host, tiled), the same slab every step"),
                    "parallelism": f"channel-sharded x{world}, one process per GPU, no data-path collective in the timed region"},
-        "roofline": roofline_obj(kms, ncalls, mode, C * nblk, f"{args.workload}:{C}x{nblk}"),
+        "roofline": roofline_obj(kms, ncalls, mode, C * nblk,
+                                 f"{args.workload}{'-noisy' if (args.ebn0 < 100.0 and args.noise_cutoff > 0) else ''}:{C}x{nblk}"),
     }
     if args.option:
         line["config"]["options"] = list(args.option)

@@ -9,10 +9,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-# the third set: the FIR stage at the headline's per-GPU batch (fir_stage_16384 of the bench line)
-for wl in full frontend frontend_16384x12; do
+# the third set: the FIR stage at the headline's per-GPU batch (fir_stage_16384 of the bench line); the fourth: the `noisy` leg's workload
+for wl in full frontend frontend_16384x12 full_noisy; do
   case $wl in
     frontend_16384x12) args="--workload frontend --channels 16384 --blocks 12" ;;
+    full_noisy) args="--workload full --ebn0 8 --noise-cutoff 6250" ;;
     *) args="--workload $wl" ;;
   esac
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$wl -- python3 $R/bench.py $args --no-cpu-baseline --no-fir-stage --no-noisy > $O/bench_trace_$wl.log 2>&1
