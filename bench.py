@@ -431,7 +431,8 @@ class CapiFanout:
 
     def gather(self, packed, offs, total, packed_all, offs_all, stream):
         totals = (self.C.c_int32 * self.world)()
-        self._chk(self.lib.m17gpu_shard_gather_packed(self.rx._ctx, self.comm, self.rank, self.world, 0, packed.data_ptr(), offs.data_ptr(),
+        self._chk(self.lib.m17gpu_shard_gather_packed(self.rx._ctx, self.comm, self.rank, self.world, 0, packed.data_ptr(),
+                                                      int(packed.shape[0]), offs.data_ptr(),
                                                       total, packed_all.data_ptr() if packed_all is not None else None,
                                                       int(packed_all.shape[0]) if packed_all is not None else 0,
                                                       offs_all.data_ptr() if offs_all is not None else None, totals,

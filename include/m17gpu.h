@@ -148,7 +148,8 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  *                            channel-block, 3 = four lanes with the DC chain and the /5 pick in registers
  *   "fir_impl"           0 | 1 = front end and timing / framer as two kernels (default); 2 = the whole FIR stage
  *                            of a channel in one wave (k_rx_fused: no discriminator stream in HBM; measured slower,
- *                            DESIGN.md section 6)
+ *                            DESIGN.md section 6); 3 = a wave per channel that runs the front end over sixteen of its
+ *                            own blocks at a time and the timing loop / framer behind it (k_rx_chan)
  * and one functional switch:
  *   "afc"                0 (default, as the reference ships: radio.cpp:8) | 1 = radio_set_afc_on(): the
  *                            NCO mixer of m17_dsp.cpp:390-408,468 with the loop of radio.cpp:196-208 per channel.
@@ -243,12 +244,22 @@ int m17gpu_shard_gather_records(m17gpu_ctx *ctx, void *comm, int rank, int world
  *   m17gpu_pack_records         d_offsets [C+1] = exclusive scan of the counts (d_offsets[C] = records in this step),
  *                               d_packed [packed_cap] = the valid records, channel-major, event order inside a channel.
  *                               Enqueued on `stream`, nothing read back.
- *   m17gpu_shard_gather_packed  every rank's packed rows land on dst_rank in d_packed_all, rank after rank, with
+ *                               packed_cap must be >= the sum of the counts: rows beyond it are NOT written, while
+ *                               d_offsets still describes all of them -- m17gpu_shard_gather_packed checks
+ *                               d_offsets[C] against the capacity it is given and refuses the step on every rank.
+ *   m17gpu_shard_gather_packed  every rank's packed rows (d_packed_mine [packed_cap_mine], the capacity given to
+ *                               m17gpu_pack_records) land on dst_rank in d_packed_all, rank after rank, with
  *                               d_offsets_all [n_channels_total + 1] the GLOBAL offsets (channel c of the node: rows
  *                               d_offsets_all[c] .. d_offsets_all[c+1]); h_totals [world] (host, may be NULL) the
- *                               records per rank.  Two grouped exchanges: the offset tables, then sum(counts) x 64 B
- *                               per rank.  The sizes of the second come from the first, so the entry synchronises
- *                               `stream` (twice on dst_rank); it runs behind the step, beside nothing.
+ *                               records per rank.  Three grouped exchanges: each rank's verdict on its own buffer with
+ *                               its offset table to dst_rank; dst_rank's verdict over all of them (and over
+ *                               packed_cap_all) back to every rank; then, only on "go", sum(counts) x 64 B per rank.
+ *                               A buffer too small ANYWHERE makes EVERY rank return M17GPU_ERR_ARG with nothing moved
+ *                               and no transfer left unmatched.  The sizes come from device memory, so the entry
+ *                               synchronises `stream` (three times); it runs behind the step, beside nothing.
+ *   m17gpu_shard_set_library    bind the fan-out entries to the library at `path` (ncclGroupStart / ncclGroupEnd /
+ *                               ncclSend / ncclRecv with RCCL's signatures) instead of the process's RCCL; NULL = the
+ *                               default.  Only before the first fan-out call of the process.
  *   m17gpu_unpack_records       packed rows + offsets back into recs [n_channels][rec_cap] + counts (rows beyond a
  *                               channel's count zeroed): the layout m17gpu_rx_blocks writes, for callers that want it.
  * (The reference has nothing to gather: one channel per process, m17_tx_rx.cpp:28-40.) */
@@ -257,8 +268,9 @@ int m17gpu_pack_records(m17gpu_ctx *ctx, const m17gpu_rec *d_recs, int rec_cap, 
 int m17gpu_unpack_records(m17gpu_ctx *ctx, const m17gpu_rec *d_packed, const int32_t *d_offsets, int n_channels,
                           m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, void *stream);
 int m17gpu_shard_gather_packed(m17gpu_ctx *ctx, void *comm, int rank, int world, int dst_rank,
-                               const m17gpu_rec *d_packed_mine, const int32_t *d_offsets_mine, int n_channels_total,
+                               const m17gpu_rec *d_packed_mine, int packed_cap_mine, const int32_t *d_offsets_mine, int n_channels_total,
                                m17gpu_rec *d_packed_all, int packed_cap_all, int32_t *d_offsets_all, int32_t *h_totals, void *stream);
+int m17gpu_shard_set_library(const char *path);
 
 /* ---------------- output wire format on the device ----------------
  * m17gpu_set_net_output attaches the sink of decode_stream_frame (m17_rx_parse.cpp:151-154 ->
@@ -318,6 +330,13 @@ int m17gen_modulate(const uint8_t *dibits, int n, int16_t *h_iq, int reset);
 int m17gpu_gen_batch(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int nblk, int n_stream_frames,
                      float ebn0_db, float noise_cutoff_hz, int16_t *d_iq, uint8_t *d_lsf, uint8_t *d_payload,
                      int max_payload_frames, int32_t *d_nframes, void *stream);
+/* The same with the generator's stages copied out for verification against a reference transmitter (both optional):
+ * d_dibits [C][nblk + 1][192] the frames as dibits (0..3; 255 = the unmodulated carrier of m17_mod_carrier,
+ * m17_modulate.cpp:88-92), d_phase [C][nblk * 1920] the modulator's phase accumulator m_acc after every sample
+ * (m17_modulate.cpp:24; 0 during the channel's start delay). */
+int m17gpu_gen_batch_stages(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int nblk, int n_stream_frames,
+                            float ebn0_db, float noise_cutoff_hz, int16_t *d_iq, uint8_t *d_lsf, uint8_t *d_payload,
+                            int max_payload_frames, int32_t *d_nframes, uint8_t *d_dibits, float *d_phase, void *stream);
 
 #ifdef __cplusplus
 }

@@ -72,7 +72,8 @@ SIGNATURES = {
     "m17gpu_parse_lsf": (_i, [_vp, _vp]),
     "m17gpu_pack_records": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "m17gpu_unpack_records": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
-    "m17gpu_shard_gather_packed": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "m17gpu_shard_gather_packed": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "m17gpu_shard_set_library": (_i, [C.c_char_p]),
     "m17gpu_set_net_output": (_i, [_vp, _vp, _i, _vp, _u64]),
     "m17gpu_shard_range": (None, [_i, _i, _i, _vp, _vp]),
     "m17gpu_shard_scatter_iq": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "m17gen_encode_call": (_u64, [C.c_char_p]),
     "m17gen_modulate": (_i, [_vp, _i, _vp, _i]),
     "m17gpu_gen_batch": (_i, [_vp, _u64, _i, _i, _i, C.c_float, C.c_float, _vp, _vp, _vp, _i, _vp, _vp]),
+    "m17gpu_gen_batch_stages": (_i, [_vp, _u64, _i, _i, _i, C.c_float, C.c_float, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

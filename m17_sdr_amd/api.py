@@ -150,9 +150,10 @@ class Receiver:
         return syms, nsyms
 
     def gen_batch(self, nblk, n_stream_frames=40, ebn0_db=200.0, base_seed=0x4D313700, first_channel=0,
-                  noise_cutoff_hz=0.0):
+                  noise_cutoff_hz=0.0, stages=False):
         """GPU-side signal source (stream mode): the same signal as generate_batch, made on the device.
-        Returns dict(iq[C,nblk,1920,2] int16 cuda, lsf[C,30], payload[C,F,16], nframes[C]) of cuda tensors."""
+        Returns dict(iq[C,nblk,1920,2] int16 cuda, lsf[C,30], payload[C,F,16], nframes[C]) of cuda tensors; with
+        stages=True also dibits[C,nblk+1,192] uint8 and phase[C,nblk*1920] float32 (m17gpu_gen_batch_stages)."""
         import torch
         dev = f"cuda:{self.device}"
         max_frames = nblk + 2
@@ -160,10 +161,18 @@ class Receiver:
         lsf = torch.zeros((self.C, 30), dtype=torch.uint8, device=dev)
         pl = torch.zeros((self.C, max_frames, 16), dtype=torch.uint8, device=dev)
         nf = torch.zeros((self.C,), dtype=torch.int32, device=dev)
+        out = {"iq": iq, "lsf": lsf, "payload": pl, "nframes": nf}
+        if stages:
+            out["dibits"] = torch.zeros((self.C, nblk + 1, 192), dtype=torch.uint8, device=dev)
+            out["phase"] = torch.zeros((self.C, nblk * 1920), dtype=torch.float32, device=dev)
+            _check(lib().m17gpu_gen_batch_stages(self._ctx, base_seed, first_channel, nblk, n_stream_frames, ebn0_db,
+                                                 noise_cutoff_hz, _ptr(iq), _ptr(lsf), _ptr(pl), max_frames, _ptr(nf),
+                                                 _ptr(out["dibits"]), _ptr(out["phase"]), self._stream()), "m17gpu_gen_batch_stages")
+            return out
         _check(lib().m17gpu_gen_batch(self._ctx, base_seed, first_channel, nblk, n_stream_frames, ebn0_db,
                                       noise_cutoff_hz, _ptr(iq), _ptr(lsf), _ptr(pl), max_frames, _ptr(nf), self._stream()),
                "m17gpu_gen_batch")
-        return {"iq": iq, "lsf": lsf, "payload": pl, "nframes": nf}
+        return out
 
     def pluto_decimate(self, wide):
         """wide: int16 cuda tensor [C, n_in, 2] at 384 kHz -> [C, n_in/8, 2] at 48 kHz (radio.cpp:18-40)."""
@@ -248,9 +257,11 @@ class Receiver:
         net = torch.zeros((self.C, rec_cap, 56), dtype=torch.uint8, device=f"cuda:{self.device}")
         if stream_ids is not None:
             self._chk(stream_ids, torch.int16, (self.C,), "stream_ids")
-        self._net, self._sids = net, stream_ids                      # keep them alive while attached
+        # the library first: a refused call (rec_cap out of range, ...) must leave the sink that IS attached -- and the
+        # tensor the context still points at -- alive
         _check(lib().m17gpu_set_net_output(self._ctx, _ptr(net), rec_cap, _ptr(stream_ids), int(dst_override)),
                "m17gpu_set_net_output")
+        self._net, self._sids = net, stream_ids                      # keep them alive while attached
         return net
 
     def clear_net_output(self):

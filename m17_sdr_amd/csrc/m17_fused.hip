@@ -245,4 +245,66 @@ void k_rx_fused(const uint4 *__restrict__ iq,              // [C][nblk][480] uin
     if (gl == 0) { cs.z0re = n0re; cs.z0im = n0im; cs.z1re = n1re; cs.z1im = n1im; }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_rx_chan (round 5; option fir_impl 3): the FIR stage of ONE CHANNEL IN ONE WAVE with the two-kernel stage's own
+// device functions -- frontend_d_tile over sixteen of the channel's OWN blocks as the tile's rows (the strictly
+// sequential DC chain then serves sixteen rows per instruction, as in k_frontend_d; k_rx_fused above has four), the
+// discriminator rows handed from the wave to itself through its slice of the workspace (written, drained, read back
+// by the same wave: L2 / Infinity Cache traffic, no other CU involved, no fence), then sync_wave_channel over those
+// blocks.  What it is for: a wave alternates between a phase that waits on memory and a phase that waits on issue
+// slots, and the waves of a SIMD drift apart, so the two phases overlap on the chip -- which two launches cannot do
+// (DESIGN.md section 6).  LDS: the front end's two tiles and the timing loop's WvChan share one region.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RC_WAVES = 8;                      // two waves per SIMD and workgroup: one of each half (STAGGER)
+constexpr int RC_LDS = 10240;                  // per wave: >= 2 x 16 x FQ_STRIDE x 4 = 8,704 B and >= sizeof(WvChan); a multiple of 2 KB (ring alignment)
+static_assert(RC_LDS >= 2 * 16 * FQ_STRIDE * 4 && RC_LDS >= (int)sizeof(WvChan) && RC_LDS % 2048 == 0, "k_rx_chan LDS layout");
+
+// the lane number as a value the compiler cannot see through: everything a phase derives from it (row and tile
+// addresses, lane masks, the framer's regroup bytes) is then computed at the head of that phase instead of being
+// hoisted in front of the group loop and held across the other phase (128 VGPRs and 24 dwords of scratch that way)
+__device__ __forceinline__ int rc_lane()
+{
+    int l = lane_id();
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
+// STAGGER: the upper half of a workgroup's waves runs its front-end phases one group AHEAD of its timing phases
+// (F0 F1 T0 F2 T1 ... T_last instead of F0 T0 F1 T1 ...): the two halves sit on the same SIMDs, and waves that start
+// together would otherwise all wait on memory together and then all want issue slots together.
+template <int STAGGER>
+__global__ __launch_bounds__(64 * RC_WAVES, 4)
+void k_rx_chan(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float *__restrict__ disc, float *__restrict__ offs,
+               int C, int nblk, int mode, m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
+               float *__restrict__ syms, int32_t *__restrict__ nsyms, float *__restrict__ fsym)
+{
+    __shared__ __attribute__((aligned(4096))) unsigned char lds[RC_WAVES][RC_LDS];
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int chan = (int)blockIdx.x * RC_WAVES + wave;
+    if (chan >= C) return;
+    uint32_t *tile = reinterpret_cast<uint32_t *>(lds[wave]);
+    float *otile = reinterpret_cast<float *>(lds[wave] + 16 * FQ_STRIDE * 4);
+    WvChan &wc = *reinterpret_cast<WvChan *>(lds[wave]);
+    const int row0 = chan * nblk, row_end = row0 + nblk;      // the channel's rows of the [C * nblk] row space
+    const bool ahead = STAGGER && wave >= RC_WAVES / 2;
+    auto front = [&](int b0) {
+        // rows b0 .. b0 + 15 of this channel (rows past its last block are computed on its last row and never stored)
+        frontend_d_tile(iq, st, disc, offs, nblk, row_end, 1, row0 + b0, tile, otile, rc_lane());
+        // the rows must be in memory before this wave reads them back (same wave, same addresses: its own stores are
+        // ordered behind its vmcnt; the loads of the timing phase are non-temporal, served by L2)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_sync();
+    };
+    if (ahead) front(0);
+    for (int b0 = 0; b0 < nblk; b0 += 16) {
+        if (!ahead) front(b0);
+        else if (b0 + 16 < nblk) front(b0 + 16);
+        sync_wave_channel(disc, offs, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, min(16, nblk - b0),
+                          chan, wc, wave, rc_lane());
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // channel state out before the next group reads it
+        wave_lds_sync();
+    }
+}
+
 } // namespace m17dev

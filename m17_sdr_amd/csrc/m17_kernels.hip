@@ -508,9 +508,9 @@ __device__ __forceinline__ float dpp_quad_left(float v)       // quad lanes (0,1
 // one tile = the 16 (channel, block) rows cb0 .. cb0 + 15; my / myo: the wave's raw and output tiles in LDS (16 x FQ_STRIDE dwords each)
 __device__ __forceinline__ void frontend_d_tile(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
                                                 float *__restrict__ disc_raw, float *__restrict__ offs,
-                                                int nblk, int total, int update_state, const int cb0, uint32_t *my, float *myo)
+                                                int nblk, int total, int update_state, const int cb0, uint32_t *my, float *myo,
+                                                const int lane = lane_id())
 {
-    const int lane = lane_id();
     const int cbl = lane >> 2, sub = lane & 3;
     if (cb0 >= total) return;
     const bool valid = (cb0 + cbl) < total;

@@ -327,14 +327,15 @@ __device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc
                        ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
                        m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
                        float *__restrict__ syms, int32_t *__restrict__ nsyms,
-                       float *__restrict__ fsym, int b0, int bcount, const int chan, WvChan &my, const int wave)
+                       float *__restrict__ fsym, int b0, int bcount, const int chan, WvChan &my, const int wave,
+                       const int lane = lane_id())
 {
     constexpr int LPC = 64;
 #ifdef M17_STAMPS
     const unsigned t_entry_ = (unsigned)__builtin_amdgcn_s_memtime();
     const unsigned long long rt_entry_ = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int gl = lane_id();
+    const int gl = lane;
     if (chan >= C) return;
     const unsigned hb = (unsigned)uni((int)(unsigned)(uintptr_t)(lds_cfp)my.H);       // LDS byte address of the ring
     ChanState &cs = st[chan];
@@ -449,6 +450,7 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                       (int)blockIdx.x * WV_WAVES + wave, chs[wave], wave);
 }
 
+#ifdef M17_STAMPS
 // EXPERIMENT (round 4, profiles/r04_pc_mock.txt): what a producer / consumer workgroup could reach at best -- twelve
 // waves run the timing kernel's whole call for twelve channels, four run the front end's tiles for the same number of
 // channel-blocks, with no hand-over between them (each role reads and writes HBM as its stand-alone kernel does): the
@@ -475,5 +477,7 @@ void k_pc_mock(const uint4 *__restrict__ iq, float *__restrict__ disc_w, float *
             frontend_d_tile(iq, st_fe, disc_w, offs_w, nblk, total, 0, ((int)blockIdx.x * tiles_per_wg + k) * 16, tile[p], otile[p]);
     }
 }
+
+#endif // M17_STAMPS (experiments stay out of the shipped library)
 
 } // namespace m17dev

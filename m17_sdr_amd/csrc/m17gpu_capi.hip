@@ -56,8 +56,11 @@ struct m17gpu_ctx {
     int sync_impl = 0;                       // 0 | 6 = timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond (default);
                                              // 7 = wave per channel at every size
     int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
+    int32_t *d_flags = nullptr;              // [n_flags] verdict words of m17gpu_shard_gather_packed
+    int n_flags = 0;
     int fir_impl = 0;                        // 0 | 1 = front end + timing kernel (default); 2 = the fused FIR-stage kernel (m17_fused.hip:
-                                             // measured 18 % slower at 16,384 x 12, kept under the parity tests)
+                                             // measured 18 % slower at 16,384 x 12, kept under the parity tests); 3 = wave per channel
+                                             // over sixteen-row tiles of its own blocks, rows through the workspace (k_rx_chan)
     std::vector<hipEvent_t> ev_pool;         // 7 events per profiled call: 5 stage marks + call start / end
     std::vector<int> ev_mode;                // mode of each profiled call
 };
@@ -219,14 +222,26 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
 
 // The FIR stage as ONE kernel (m17_fused.hip): front end, timing loop and framer of a channel in one wave, the
 // discriminator samples never leaving the CU.  Not the default: DESIGN.md section 6 (round 4) has the measurements.
-bool use_fused(const m17gpu_ctx *ctx) { return !ctx->afc && ctx->fir_impl == 2; }
+bool use_fused(const m17gpu_ctx *ctx) { return !ctx->afc && (ctx->fir_impl >= 2); }
 int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
                  int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_rx_fused, dim3(cdiv(ctx->C, FU_WAVES)), dim3(64 * FU_WAVES), 0, st,
-                       reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->C, nblk, mode,
-                       reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
-                       d_syms, d_nsyms, ctx->d_fsym);
+    if (ctx->fir_impl == 4)
+        hipLaunchKernelGGL(k_rx_chan<1>, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
+                           reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->C, nblk, mode,
+                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
+                           d_syms, d_nsyms, ctx->d_fsym);
+    else if (ctx->fir_impl == 3)
+        // wave per channel, sixteen of its own blocks per front-end tile, rows handed over through the workspace (k_rx_chan)
+        hipLaunchKernelGGL(k_rx_chan<0>, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
+                           reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->C, nblk, mode,
+                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
+                           d_syms, d_nsyms, ctx->d_fsym);
+    else
+        hipLaunchKernelGGL(k_rx_fused, dim3(cdiv(ctx->C, FU_WAVES)), dim3(64 * FU_WAVES), 0, st,
+                           reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->C, nblk, mode,
+                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
+                           d_syms, d_nsyms, ctx->d_fsym);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -324,7 +339,7 @@ void m17gpu_destroy(m17gpu_ctx *ctx)
     if (!ctx) return;
     DeviceScope dev_scope_(ctx->device);
     void *bufs[] = {ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->d_fsym, ctx->d_work,
-                    ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis, ctx->d_dec_hist};
+                    ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis, ctx->d_dec_hist, ctx->d_flags};
     for (void *p : bufs) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -408,6 +423,7 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
     return M17GPU_OK;
 }
 
+#ifdef M17_STAMPS
 // EXPERIMENT (not in the header): k_pc_mock on the context's discriminator stream -- call m17gpu_rx_blocks(mode 0) on the
 // same d_iq first, so that the producers rewrite what is already there.  One launch = the front end's and the timing
 // kernel's work of one step, co-resident.
@@ -422,7 +438,6 @@ int m17gpu_debug_pc_mock(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *
     return M17GPU_OK;
 }
 
-#ifdef M17_STAMPS
 int m17gpu_debug_stamps(unsigned long long *out)
 {
     HIPCHK(hipDeviceSynchronize());
@@ -493,7 +508,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     auto bad = [&]() { return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: value out of range for ") + name); };
     if (!std::strcmp(name, "sync_impl")) { if (value != 0 && value != 6 && value != 7) return bad(); ctx->sync_impl = value; }
     else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 3) return bad(); ctx->fe_impl = value; }
-    else if (!std::strcmp(name, "fir_impl")) { if (value < 0 || value > 2) return bad(); ctx->fir_impl = value; }
+    else if (!std::strcmp(name, "fir_impl")) { if (value < 0 || value > 4) return bad(); ctx->fir_impl = value; }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
 #ifdef M17_STAMPS
     else if (!std::strcmp(name, "fe_debug")) { ctx->fe_debug = value; }      // instrumented build only: WRONG results
@@ -544,16 +559,26 @@ struct RcclApi {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
+std::mutex g_rccl_mu;
+std::string g_rccl_path;            // m17gpu_shard_set_library: bind this library instead of the process's RCCL
+bool g_rccl_bound = false;
 const RcclApi &rccl()
 {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
         void *h = nullptr;
-        for (const char *name : {"librccl.so", "librccl.so.1"})
-            if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);                 // whichever RCCL the process already runs on
-        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        {
+            std::lock_guard<std::mutex> lk(g_rccl_mu);
+            g_rccl_bound = true;
+            if (!g_rccl_path.empty()) h = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+            else {
+                for (const char *name : {"librccl.so", "librccl.so.1"})
+                    if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);             // whichever RCCL the process already runs on
+                if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            }
+        }
         if (!h) return;
         api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(h, "ncclGroupStart"));
         api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
@@ -703,11 +728,12 @@ int m17gpu_unpack_records(m17gpu_ctx *ctx, const m17gpu_rec *d_packed, const int
 // rank reads back its own total; the gathering rank the others' totals): it runs after the step, beside nothing.
 // h_totals [world] (host, may be NULL) receives the per-rank record counts on dst_rank.
 int m17gpu_shard_gather_packed(m17gpu_ctx *ctx, void *comm, int rank, int world, int dst_rank,
-                               const m17gpu_rec *d_packed_mine, const int32_t *d_offsets_mine, int n_channels_total,
+                               const m17gpu_rec *d_packed_mine, int packed_cap_mine, const int32_t *d_offsets_mine, int n_channels_total,
                                m17gpu_rec *d_packed_all, int packed_cap_all, int32_t *d_offsets_all, int32_t *h_totals, void *stream)
 {
     if (!ctx || !comm || world <= 0 || rank < 0 || rank >= world || dst_rank < 0 || dst_rank >= world || n_channels_total <= 0 ||
-        !d_packed_mine || !d_offsets_mine || (rank == dst_rank && (!d_packed_all || !d_offsets_all || packed_cap_all <= 0)))
+        !d_packed_mine || packed_cap_mine <= 0 || !d_offsets_mine ||
+        (rank == dst_rank && (!d_packed_all || !d_offsets_all || packed_cap_all <= 0)))
         return fail(M17GPU_ERR_ARG, "m17gpu_shard_gather_packed: bad argument");
     int lo, hi;
     m17gpu_shard_range(rank, world, n_channels_total, &lo, &hi);
@@ -718,40 +744,80 @@ int m17gpu_shard_gather_packed(m17gpu_ctx *ctx, void *comm, int rank, int world,
     hipStream_t st = S(stream);
     ncclComm_t cm = static_cast<ncclComm_t>(comm);
     std::string grp_err;
-    // leg 1: the local offset tables ([Cr + 1] int32 each) to the gathering rank, behind one another
+    // Whether the exchange can go through is decided by ALL ranks before any record moves: a rank that left alone
+    // between the two exchanges -- its own capacity too small, or the gathering rank's -- would leave its peers with a
+    // send nobody receives (round 4's form did, on the gathering rank).  So: every rank reads its own total and checks it
+    // against its own buffer; the verdicts travel to the gathering rank with the offset tables; its verdict over
+    // everything travels back; the records move only if that is "go", and otherwise every rank returns M17GPU_ERR_ARG.
+    // flags[0] = this rank's verdict (out) / the gathering rank's verdict (in), flags[1 ..] = the peers' verdicts on dst_rank
+    if (!ctx->d_flags || ctx->n_flags < world + 1) {
+        (void)hipFree(ctx->d_flags);
+        ctx->d_flags = nullptr; ctx->n_flags = 0;
+        HIPCHK(hipMalloc(&ctx->d_flags, sizeof(int32_t) * (size_t)(world + 1)));
+        ctx->n_flags = world + 1;
+    }
+    int32_t mine_total = 0;
+    HIPCHK(hipMemcpyAsync(&mine_total, d_offsets_mine + (hi - lo), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int32_t my_ok = (mine_total >= 0 && mine_total <= packed_cap_mine) ? 1 : 0;    // m17gpu_pack_records drops rows beyond its packed_cap
+    HIPCHK(hipMemcpyAsync(ctx->d_flags, &my_ok, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    // leg 1: verdicts and local offset tables ([Cr] int32 each) to the gathering rank
     RCCLCHK(R.GroupStart());
     if (rank == dst_rank) {
         for (int r = 0; r < world; ++r) {
             int a, b;
             m17gpu_shard_range(r, world, n_channels_total, &a, &b);
-            if (r == dst_rank || b <= a) continue;
-            RCCLGRP(R.Recv(d_offsets_all + a + 1, (size_t)(b - a), ncclInt32, r, cm, st));      // local offs[1 .. Cr]; shifted below
+            if (r == dst_rank) continue;
+            RCCLGRP(R.Recv(ctx->d_flags + 1 + r, 1, ncclInt32, r, cm, st));
+            if (b > a) RCCLGRP(R.Recv(d_offsets_all + a + 1, (size_t)(b - a), ncclInt32, r, cm, st));    // local offs[1 .. Cr]; shifted below
         }
-    } else if (hi > lo) {
-        RCCLGRP(R.Send(d_offsets_mine + 1, (size_t)(hi - lo), ncclInt32, dst_rank, cm, st));
+    } else {
+        RCCLGRP(R.Send(ctx->d_flags, 1, ncclInt32, dst_rank, cm, st));
+        if (hi > lo) RCCLGRP(R.Send(d_offsets_mine + 1, (size_t)(hi - lo), ncclInt32, dst_rank, cm, st));
     }
     RCCLGRP(R.GroupEnd());
     if (!grp_err.empty()) return fail(M17GPU_ERR_HIP, grp_err);
-    int32_t mine_total = 0;
-    HIPCHK(hipMemcpyAsync(&mine_total, d_offsets_mine + (hi - lo), sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    std::vector<int32_t> totals((size_t)world, 0);
+    std::vector<int32_t> totals((size_t)world, 0), oks((size_t)world, 1);
+    int32_t go = 1;
+    std::string why;
     if (rank == dst_rank) {
         if (hi > lo) HIPCHK(hipMemcpyAsync(d_offsets_all + lo + 1, d_offsets_mine + 1, (size_t)(hi - lo) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         for (int r = 0; r < world; ++r) {                       // each rank's total = its last local offset
             int a, b;
             m17gpu_shard_range(r, world, n_channels_total, &a, &b);
             if (b > a) HIPCHK(hipMemcpyAsync(&totals[r], d_offsets_all + b, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            if (r != dst_rank) HIPCHK(hipMemcpyAsync(&oks[r], ctx->d_flags + 1 + r, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         }
+        HIPCHK(hipStreamSynchronize(st));
+        oks[rank] = my_ok;
+        long long sum = 0;
+        for (int r = 0; r < world; ++r) {
+            sum += totals[r];
+            if (!oks[r] && go) { go = 0; why = "rank " + std::to_string(r) + " packed more records than its d_packed_mine holds"; }
+        }
+        if (go && sum > packed_cap_all) { go = 0; why = "d_packed_all is too small for this step's records"; }
+        HIPCHK(hipMemcpyAsync(ctx->d_flags, &go, sizeof(int32_t), hipMemcpyHostToDevice, st));
     }
-    HIPCHK(hipStreamSynchronize(st));
-    if (rank != dst_rank) totals[rank] = mine_total;
+    // leg 1.5: the verdict back to every peer
+    RCCLCHK(R.GroupStart());
+    if (rank == dst_rank) {
+        for (int r = 0; r < world; ++r)
+            if (r != dst_rank) RCCLGRP(R.Send(ctx->d_flags, 1, ncclInt32, r, cm, st));
+    } else {
+        RCCLGRP(R.Recv(ctx->d_flags, 1, ncclInt32, dst_rank, cm, st));
+    }
+    RCCLGRP(R.GroupEnd());
+    if (!grp_err.empty()) return fail(M17GPU_ERR_HIP, grp_err);
+    if (rank != dst_rank) {
+        HIPCHK(hipMemcpyAsync(&go, ctx->d_flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        totals[rank] = mine_total;
+    }
+    HIPCHK(hipStreamSynchronize(st));              // (dst_rank: the verdict's source word stays untouched until the sends have read it)
+    if (!go)
+        return fail(M17GPU_ERR_ARG, "m17gpu_shard_gather_packed: refused on every rank, nothing moved: " +
+                                    (why.empty() ? std::string("a packed buffer is too small for this step's records (see the gathering rank)") : why));
     // leg 2: the records themselves, sum(counts) rows per rank
     long long base = 0;
-    if (rank == dst_rank) {
-        long long sum = 0;
-        for (int r = 0; r < world; ++r) sum += totals[r];
-        if (sum > packed_cap_all) return fail(M17GPU_ERR_ARG, "m17gpu_shard_gather_packed: d_packed_all is too small for this step's records");
-    }
     RCCLCHK(R.GroupStart());
     if (rank == dst_rank) {
         for (int r = 0; r < world; ++r) {
@@ -782,6 +848,17 @@ int m17gpu_shard_gather_packed(m17gpu_ctx *ctx, void *comm, int rank, int world,
         HIPCHK(hipGetLastError());
         if (h_totals) std::memcpy(h_totals, totals.data(), sizeof(int32_t) * (size_t)world);
     }
+    return M17GPU_OK;
+}
+
+// Bind the fan-out entries to THIS library (any library with RCCL's ncclGroupStart / ncclGroupEnd / ncclSend / ncclRecv:
+// a host application's own RCCL build, a test transport) instead of the RCCL the process already runs on.  Before
+// the first fan-out call only: once bound, the choice stands for the life of the process.
+int m17gpu_shard_set_library(const char *path)
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl_bound) return fail(M17GPU_ERR_ARG, "m17gpu_shard_set_library: the fan-out entries are already bound to a library");
+    g_rccl_path = path ? path : "";
     return M17GPU_OK;
 }
 
@@ -876,6 +953,17 @@ int m17gpu_gen_batch(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int
                      float ebn0_db, float noise_cutoff_hz, int16_t *d_iq, uint8_t *d_lsf, uint8_t *d_payload,
                      int max_payload_frames, int32_t *d_nframes, void *stream)
 {
+    return m17gpu_gen_batch_stages(ctx, base_seed, first_channel, nblk, n_stream_frames, ebn0_db, noise_cutoff_hz, d_iq, d_lsf,
+                                   d_payload, max_payload_frames, d_nframes, nullptr, nullptr, stream);
+}
+
+// The same with the generator's intermediate stages copied out, so that each can be compared with the oracle's
+// transmitter on its own: d_dibits [C][nblk + 1][192] (0..3, 255 = unmodulated carrier) as m17_fmt_add_* built them,
+// d_phase [C][nblk * 1920] the modulator's m_acc after every sample (before the per-symbol wrap; 0 during the start delay).
+int m17gpu_gen_batch_stages(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int nblk, int n_stream_frames,
+                            float ebn0_db, float noise_cutoff_hz, int16_t *d_iq, uint8_t *d_lsf, uint8_t *d_payload,
+                            int max_payload_frames, int32_t *d_nframes, uint8_t *d_dibits, float *d_phase, void *stream)
+{
     if (!ctx || !d_iq || nblk <= 0 || n_stream_frames < 0 || (d_payload && max_payload_frames <= 0))
         return fail(M17GPU_ERR_ARG, "m17gpu_gen_batch: bad argument");
     ON_CTX_DEVICE(ctx);
@@ -928,8 +1016,12 @@ int m17gpu_gen_batch(m17gpu_ctx *ctx, uint64_t base_seed, int first_channel, int
                            d_lsf ? d_lsf + (size_t)c0 * 30 : nullptr,
                            d_payload ? d_payload + (size_t)c0 * max_payload_frames * 16 : nullptr, max_payload_frames,
                            d_nframes ? d_nframes + c0 : nullptr);
+        if (d_dibits)
+            HIPCHK(hipMemcpyAsync(d_dibits + (size_t)c0 * A.nslots * 192, d_sym, (size_t)cn * A.nslots * 192, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_gen_sum, dim3(cdiv((long long)cn * want, 256)), dim3(256), 0, st, A, d_sym, d_taps, d_sum);
         hipLaunchKernelGGL(k_gen_phase, dim3(cdiv(cn, 64)), dim3(64), 0, st, A, d_sum);
+        if (d_phase)
+            HIPCHK(hipMemcpyAsync(d_phase + (size_t)c0 * want, d_sum, sizeof(float) * (size_t)cn * want, hipMemcpyDeviceToDevice, st));
         const int segs = (int)((want + GEN_SEG - 1) / GEN_SEG);
         hipLaunchKernelGGL(k_gen_iq, dim3((unsigned)((long long)cn * segs)), dim3(GEN_SEG), 0, st, A, NZ, d_sum,
                            d_iq + (size_t)c0 * want * 2);

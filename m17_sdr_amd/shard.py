@@ -64,6 +64,8 @@ def gather_packed(packed, offsets, dst=0, group=None):
     offsets [Cr + 1] int32 (exclusive scan of the rank's per-channel counts).  Two exchanges: the offset tables
     (4 bytes per channel) and sum(counts) x 64 bytes per rank -- nothing of the unused record capacity moves.  The row
     counts size the second exchange, so every rank reads its own total back (one host sync per step, behind the step).
+    A rank whose `packed` is smaller than its offsets[-1] rows makes the call raise ValueError on EVERY rank before
+    anything moves.
     Returns (packed_all [sum, 64], offsets_all [C + 1] GLOBAL offsets, totals list) on dst, (None, None, None) elsewhere."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
@@ -71,11 +73,18 @@ def gather_packed(packed, offsets, dst=0, group=None):
     direct = _moves_device_tensors(group) or home.type == "cpu"
     wire = home if direct else torch.device("cpu")
     n_mine = int(offsets[-1].item())
-    meta = torch.tensor([offsets.shape[0] - 1, n_mine], dtype=torch.int64, device=wire)
+    # Receiver.pack_records / m17gpu_pack_records write no row beyond the capacity of `packed` while `offsets` still
+    # counts them all: a rank whose step outgrew its buffer says so in the exchange every rank takes part in, and then
+    # EVERY rank raises -- none is left in a send or a receive that has no partner
+    meta = torch.tensor([offsets.shape[0] - 1, n_mine, 1 if 0 <= n_mine <= packed.shape[0] else 0], dtype=torch.int64, device=wire)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
     chans = [int(t[0].item()) for t in metas]
     totals = [int(t[1].item()) for t in metas]
+    short = [r for r, t in enumerate(metas) if int(t[2].item()) == 0]
+    if short:
+        raise ValueError(f"gather_packed: rank(s) {short} packed more records than their buffer holds ({totals}); "
+                         "refused on every rank, nothing moved")
     ops, keep = [], []
     if rank == dst:
         offs_all = torch.zeros((sum(chans) + 1,), dtype=torch.int32, device=wire)

@@ -905,6 +905,191 @@ void m17o_pluto_decimate(int16_t *hist, const int16_t *in, int n_in, int16_t *ou
     }
 }
 
+/* ------------------------------------------------------------------ */
+/* Transmit side: frame builders + 4-FSK RRC modulator.   */
+/* The checker of the product's signal source (m17_txgen.cpp host,      */
+/* m17_gen.hip device).  Not on the receive hot path.                   */
+/* ------------------------------------------------------------------ */
+/* pack_16_to_2 (m17_bit_utils.cpp:74-85) */
+static int tx_pack_16_to_2(uint16_t in, uint8_t *out)
+{
+    for (int i = 0; i < 8; i++) out[i] = (uint8_t)((in >> (14 - 2 * i)) & 0x03);
+    return 8;
+}
+/* pack_1_to_2 (m17_bit_utils.cpp:19-25) */
+static int tx_pack_1_to_2(const uint8_t *in, uint8_t *out, int len)
+{
+    int idx = 0;
+    for (int i = 0; i < len; i += 2) out[idx++] = (uint8_t)((in[i] << 1) | in[i + 1]);
+    return idx;
+}
+
+/* build_lich (m17_tx_routines.cpp:38-54): pack_48_to_8 dest, src (m17_bit_utils.cpp:33-41), the packed type word
+ * (m17_pack_type, :230-244, passed in packed), 14 meta bytes, CRC-16 big-endian.  Returns 30. */
+int m17o_build_lsf(uint64_t dst, uint64_t src, uint16_t type_word, const uint8_t *meta, uint8_t *lsf)
+{
+    int idx = 0;
+    for (int i = 0; i < 6; i++) lsf[idx++] = (uint8_t)((dst >> (40 - 8 * i)) & 0xFF);
+    for (int i = 0; i < 6; i++) lsf[idx++] = (uint8_t)((src >> (40 - 8 * i)) & 0xFF);
+    lsf[idx++] = (uint8_t)((type_word >> 8) & 0xFF);
+    lsf[idx++] = (uint8_t)(type_word & 0xFF);
+    for (int i = 0; i < 14; i++) lsf[idx++] = meta[i];
+    uint16_t crc = m17o_crc(lsf, idx);
+    lsf[idx++] = (uint8_t)(crc >> 8);
+    lsf[idx++] = (uint8_t)(crc & 0xFF);
+    return idx;
+}
+
+/* m17_fmt_add_tx_preamble (m17_tx_routines.cpp:24-31) */
+int m17o_preamble_dibits(uint8_t *dibits)
+{
+    int idx = 0;
+    for (int i = 0; i < 192 / 2; i++) { dibits[idx++] = 0x01; dibits[idx++] = 0x03; }
+    return idx;
+}
+
+/* m17_fmt_add_eot (m17_tx_routines.cpp:242-255) */
+int m17o_eot_dibits(uint8_t *dibits)
+{
+    int idx = 0;
+    for (int i = 0; i < 24; i++) {
+        for (int k = 0; k < 6; k++) dibits[idx++] = 0x01;
+        dibits[idx++] = 0x03;
+        dibits[idx++] = 0x01;
+    }
+    return idx;
+}
+
+/* m17_fmt_add_link_setup_frame (m17_tx_routines.cpp:92-117) behind build_lich: conv_encode_8 of the 30 LSF bytes
+ * (488 bits), P1 puncture (368), interleave, de-correlate, sync word 0x55F7 + 184 dibits.
+ * reference_quirks = 0 (default of every caller in tests/): the frame the code sets out to build, each stage in a
+ *   buffer of its own -- what the M17 specification describes.
+ * reference_quirks = 1: the reference's `uint8_t tx_bit[2][388]` (:93) as it lies in memory: 488 coded bits run
+ *   100 bytes into tx_bit[1], which m17_punc_p1 (m17_puncture.cpp:12-21) is overwriting with its own output while it
+ *   still reads tx_bit[0][388..487] from there -- the last 100 coded bits it punctures are its own early output.
+ *   The reference's receiver never notices: decode_link_frame's CRC gate drops the LSF content. */
+int m17o_lsf_frame_dibits(const uint8_t *lsf, uint8_t *dibits, int reference_quirks)
+{
+    uint8_t flat[2 * 388 + 128], wide0[512], wide1[512];
+    uint8_t *tx0 = reference_quirks ? flat : wide0;
+    uint8_t *tx1 = reference_quirks ? flat + 388 : wide1;
+    int len = m17o_conv_encode_8(lsf, tx0, 30);
+    len = m17o_punc(1, tx0, tx1, len);
+    m17o_interleave_u8(tx1, tx0, len);
+    m17o_de_correlate_u8(tx0, tx1, len);
+    int idx = tx_pack_16_to_2(0x55F7, dibits);
+    idx += tx_pack_1_to_2(tx1, &dibits[idx], len);
+    return idx;
+}
+
+/* m17_fmt_add_stream_frame (m17_tx_routines.cpp:143-187): five LICH bytes + counter byte as four Golay words (96
+ * bits), FN + 16 payload bytes conv-encoded (296) and P2-punctured in place (272), interleave, de-correlate, sync word
+ * 0xFF5D.  lich_count and fn are the caller's m_lich_count / m_fn (the reference advances them itself, :155,:170).
+ * (The reference's txb[0] is overrun here too -- 96 + 296 = 392 > 388 -- but the in-place puncture reads every bit
+ * before anything is written over it, so its output is the specified one: no quirk to restate.) */
+int m17o_stream_frame_dibits(const uint8_t *lsf, int lich_count, uint16_t fn, const uint8_t *payload, uint8_t *dibits)
+{
+    uint8_t tmp[80], txb0[512], txb1[512];
+    int idx = 0;
+    for (int i = 0; i < 5; i++) tmp[idx++] = lsf[lich_count * 5 + i];
+    tmp[idx++] = (uint8_t)((lich_count & 0x07) << 5);
+    /* pack_8_to_12_x4 (m17_bit_utils.cpp:132-149) */
+    uint16_t dw[4];
+    dw[0] = (uint16_t)((tmp[0] << 4) | ((tmp[1] >> 4) & 0x0F));
+    dw[1] = (uint16_t)(((tmp[1] & 0x0F) << 8) | tmp[2]);
+    dw[2] = (uint16_t)((tmp[3] << 4) | ((tmp[4] >> 4) & 0x0F));
+    dw[3] = (uint16_t)(((tmp[4] & 0x0F) << 8) | tmp[5]);
+    int len = 0;
+    for (int i = 0; i < 4; i++) {
+        uint32_t dpw = m17o_golay_encode(dw[i]);
+        for (uint32_t m = 0x800000; m; m >>= 1) txb0[len++] = (dpw & m) ? 1 : 0;      /* pack_24_to_1 :63-69 */
+    }
+    const int fn_start = len;
+    tmp[0] = (uint8_t)(fn >> 8); tmp[1] = (uint8_t)(fn & 0xFF);
+    for (int i = 0; i < 16; i++) tmp[2 + i] = payload[i];
+    len = m17o_conv_encode_8(tmp, &txb0[fn_start], 18);
+    len = m17o_punc(2, &txb0[fn_start], &txb0[fn_start], len);
+    m17o_interleave_u8(txb0, txb1, len + fn_start);
+    m17o_de_correlate_u8(txb1, txb0, len + fn_start);
+    idx = tx_pack_16_to_2(0xFF5D, dibits);
+    idx += tx_pack_1_to_2(txb0, &dibits[idx], len + fn_start);
+    return idx;
+}
+
+/* m17_fmt_add_packet (m17_tx_routines.cpp:201-222): up to 25 payload bytes, byte 25 = EOF flag | nf << 2 (nf is an
+ * uint8_t in the reference, not masked), conv_encode_8 of 26 bytes (424 bits), P3 puncture of the first 420 (368),
+ * interleave, de-correlate, sync word 0x75FF.  reference_quirks as for the link-setup frame: `txb[2][388]` (:203)
+ * takes 424 coded bits, and m17_punc_p3 reads txb[0][388..419] out of the row it is writing. */
+int m17o_packet_frame_dibits(const uint8_t *payload, int len, int eof, int nf, uint8_t *dibits, int reference_quirks)
+{
+    uint8_t tmp[80], flat[2 * 388 + 128], wide0[512], wide1[512];
+    if (len > 25 || len < 0) return 0;
+    uint8_t *t0 = reference_quirks ? flat : wide0;
+    uint8_t *t1 = reference_quirks ? flat + 388 : wide1;
+    memset(tmp, 0, 25);
+    memcpy(tmp, payload, (size_t)len);
+    tmp[25] = eof ? 0x80 : 0x00;
+    tmp[25] |= (uint8_t)(nf << 2);
+    m17o_conv_encode_8(tmp, t0, 26);
+    m17o_punc(3, t0, t1, 420);
+    m17o_interleave_u8(t1, t0, 368);
+    m17o_de_correlate_u8(t0, t1, 368);
+    tx_pack_16_to_2(0x75FF, dibits);
+    tx_pack_1_to_2(t1, &dibits[8], 368);
+    return M17O_FRAME_SYMS;
+}
+
+/* m17_mod_init (m17_modulate.cpp:65-77) at radio_get_oversample() == 10 (radio.cpp:207-215, LimeSDR) */
+void m17o_mod_init(m17o_mod *m)
+{
+    memset(m, 0, sizeof *m);
+    m17o_build_rrc_filter(m->c, 0.5f, M17O_TX_FN * M17O_TX_OS, M17O_TX_OS);
+    m17o_set_filter_gain(m->c, 10, 1, M17O_TX_FN * M17O_TX_OS);
+    /* m_tx_lu (m17_modulate.cpp:9): float initialisers from double expressions */
+    m->lu[0] = (float)(M_PI / 30.0); m->lu[1] = (float)(M_PI / 10.0);
+    m->lu[2] = (float)(-M_PI / 30); m->lu[3] = (float)(-M_PI / 10.0);
+}
+
+/* one symbol: mod_filter (m17_modulate.cpp:49-61) + sub_filter (:42-48) + mod_fsk (:22-38).  cos / sin of the float
+ * m_acc under <math.h> in C++ are the float overloads, and float * int (0x3FFF) stays float: cosf / sinf here.
+ * sums / phases (optional, 10 floats each): the filter outputs and m_acc after each sample, before the wrap. */
+static void mod_symbol(m17o_mod *m, float sample, int16_t *iq, float *sums, float *phases)
+{
+    const int os = M17O_TX_OS;
+    float sum[M17O_TX_OS];
+    for (int i = 0; i < M17O_TX_FN - 1; i++) m->s[i] = m->s[i + 1];
+    m->s[M17O_TX_FN - 1] = sample;
+    for (int i = 0, n = os - 1; i < os; i++, n--) {
+        const float *c = &m->c[n];
+        float a = m->s[0] * c[0];
+        for (int j = 1; j < M17O_TX_FN; j++) a += m->s[j] * c[j * os];
+        sum[i] = a;
+    }
+    for (int i = 0; i < os; i++) {
+        m->acc += sum[i];
+        iq[2 * i]     = (int16_t)(cosf(m->acc) * 0x3FFF);
+        iq[2 * i + 1] = (int16_t)(sinf(m->acc) * 0x3FFF);
+        if (sums) sums[i] = sum[i];
+        if (phases) phases[i] = m->acc;
+    }
+    /* phase accumulator wrap (:33-37): float / double -> float, modf on the promoted value, float * double -> float */
+    m->acc = (float)(m->acc / (2.0 * M_PI));
+    double ip;
+    m->acc = (float)modf((double)m->acc, &ip);
+    m->acc = (float)(m->acc * 2.0 * M_PI);
+}
+
+/* m17_mod_dibits (m17_modulate.cpp:80-84) / m17_mod_carrier (:88-92: a dibit value of 255 here): n symbols in,
+ * 10 n IQ samples out */
+int m17o_modulate(m17o_mod *m, const uint8_t *dibits, int n, int16_t *iq, float *sums, float *phases)
+{
+    for (int i = 0; i < n; i++)
+        mod_symbol(m, dibits[i] == 255 ? 0.0f : m->lu[dibits[i] & 3], iq + (size_t)i * 2 * M17O_TX_OS,
+                   sums ? sums + (size_t)i * M17O_TX_OS : NULL, phases ? phases + (size_t)i * M17O_TX_OS : NULL);
+    return n * M17O_TX_OS;
+}
+int m17o_sizeof_mod(void) { return (int)sizeof(m17o_mod); }
+
 int m17o_rx_blocks_net(m17o_chan *st, int C, int nblk, const int16_t *iq,
                        m17o_rec *recs, int cap, int32_t *counts,
                        float *syms, int32_t *nsyms, int mode, int nthreads,

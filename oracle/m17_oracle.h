@@ -167,6 +167,28 @@ int  m17o_sizeof_chan(void);
 void m17o_set_afc(m17o_chan *st, int on);
 void m17o_get_afc(const m17o_chan *st, float *delta, double *acc);
 
+/* ---- transmit side: the checker of the product's signal source ----
+ * frame builders of m17_tx_routines.cpp:24-255 and the 4-FSK RRC modulator of m17_modulate.cpp:22-92 (10 samples per
+ * symbol).  reference_quirks: 0 = the frame as specified; 1 = with the reference's tx_bit[2][388] / txb[2][388]
+ * overrun restated (m17_tx_routines.cpp:93,203: the link-setup and packet frames the reference really sends). */
+#define M17O_TX_FN 31             /* m17_modulate.cpp:6 TX_FN */
+#define M17O_TX_OS 10             /* radio_get_oversample(), radio.cpp:207-215 */
+typedef struct {
+    float c[M17O_TX_FN * M17O_TX_OS];   /* m_tx_c */
+    float s[M17O_TX_FN];                /* m_tx_s */
+    float lu[4];                        /* m_tx_lu */
+    float acc;                          /* m_acc */
+} m17o_mod;
+int  m17o_build_lsf(uint64_t dst, uint64_t src, uint16_t type_word, const uint8_t *meta, uint8_t *lsf);
+int  m17o_preamble_dibits(uint8_t *dibits);
+int  m17o_eot_dibits(uint8_t *dibits);
+int  m17o_lsf_frame_dibits(const uint8_t *lsf, uint8_t *dibits, int reference_quirks);
+int  m17o_stream_frame_dibits(const uint8_t *lsf, int lich_count, uint16_t fn, const uint8_t *payload, uint8_t *dibits);
+int  m17o_packet_frame_dibits(const uint8_t *payload, int len, int eof, int nf, uint8_t *dibits, int reference_quirks);
+void m17o_mod_init(m17o_mod *m);
+int  m17o_modulate(m17o_mod *m, const uint8_t *dibits, int n, int16_t *iq, float *sums, float *phases);
+int  m17o_sizeof_mod(void);
+
 /* ---- wide-band ingest (radio.cpp:18-51,157-177): 31-tap symmetric /8 decimator, Q15 ---- */
 void m17o_pluto_build_dec_filter(int16_t *coffs /* [31] */);
 void m17o_pluto_decimate(int16_t *hist /* [31][2] state */, const int16_t *in /* [n_in][2] */, int n_in,

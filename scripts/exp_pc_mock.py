@@ -3,6 +3,8 @@ kernel's work of a step in ONE launch, co-resident (12 timing waves + 4 front-en
    python scripts/exp_pc_mock.py [channels] [blocks]"""
 import sys, os, ctypes as C, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import m17_sdr_amd._lib as L_
+L_.LIB_PATH = L_.LIB_PATH.replace("libm17gpu.so", "libm17gpu_stamps.so")     # the experiment lives in the instrumented build only (make stamps)
 import m17_sdr_amd as m
 Cn = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 nblk = int(sys.argv[2]) if len(sys.argv) > 2 else 12

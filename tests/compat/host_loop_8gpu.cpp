@@ -47,7 +47,7 @@ int run_rank(m17gpu_ctx *rx, ncclComm_t comm, int rank, int world, int TOTAL, in
         if ((rc = m17gpu_rx_blocks(rx, B.d_iq_mine[cur], NBLK, /*full chain*/ 1, B.d_recs_mine, cap, B.d_cnt_mine, nullptr, nullptr, s)) != M17GPU_OK) return rc;
         hipEventRecord(ev_free[cur], s);
         if ((rc = m17gpu_pack_records(rx, B.d_recs_mine, cap, B.d_cnt_mine, B.d_packed_mine, (hi - lo) * cap, B.d_offs_mine, s)) != M17GPU_OK) return rc;
-        if ((rc = m17gpu_shard_gather_packed(rx, comm, rank, world, 0, B.d_packed_mine, B.d_offs_mine, TOTAL,
+        if ((rc = m17gpu_shard_gather_packed(rx, comm, rank, world, 0, B.d_packed_mine, (hi - lo) * cap, B.d_offs_mine, TOTAL,
                                              B.d_packed_all, TOTAL * cap, B.d_offs_all, totals, s)) != M17GPU_OK) return rc;
         hipStreamSynchronize(s);
         // rank 0: channel c's records of this step are rows d_offs_all[c] .. d_offs_all[c+1] of d_packed_all

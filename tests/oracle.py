@@ -138,3 +138,87 @@ def demap(sym):
     out = np.zeros(368, np.float32)
     L().m17o_demap_frame(vp(sym), vp(out))
     return out
+
+
+# ---- transmit side (oracle/m17_oracle.c "Transmit side"): the checker of the product's signal source ----
+def tx_build_lsf(dst, src, type_word, meta=None):
+    meta = np.zeros(14, np.uint8) if meta is None else np.ascontiguousarray(meta, np.uint8)
+    lsf = np.zeros(30, np.uint8)
+    assert L().m17o_build_lsf(C.c_uint64(int(dst)), C.c_uint64(int(src)), C.c_uint16(int(type_word)), vp(meta), vp(lsf)) == 30
+    return lsf
+
+
+def tx_lsf_frame(lsf, reference_quirks=0):
+    d = np.zeros(192, np.uint8)
+    assert L().m17o_lsf_frame_dibits(vp(np.ascontiguousarray(lsf, np.uint8)), vp(d), int(reference_quirks)) == 192
+    return d
+
+
+def tx_stream_frame(lsf, lich_count, fn, payload):
+    d = np.zeros(192, np.uint8)
+    assert L().m17o_stream_frame_dibits(vp(np.ascontiguousarray(lsf, np.uint8)), int(lich_count), C.c_uint16(int(fn)),
+                                        vp(np.ascontiguousarray(payload, np.uint8)), vp(d)) == 192
+    return d
+
+
+def tx_packet_frame(payload, length, eof, nf, reference_quirks=0):
+    d = np.zeros(192, np.uint8)
+    buf = np.zeros(32, np.uint8)
+    buf[:len(payload)] = payload
+    n = L().m17o_packet_frame_dibits(vp(buf), int(length), int(eof), int(nf), vp(d), int(reference_quirks))
+    return d if n == 192 else None
+
+
+def tx_preamble():
+    d = np.zeros(192, np.uint8)
+    assert L().m17o_preamble_dibits(vp(d)) == 192
+    return d
+
+
+def tx_eot():
+    d = np.zeros(192, np.uint8)
+    assert L().m17o_eot_dibits(vp(d)) == 192
+    return d
+
+
+class Modulator:
+    """m17_mod_init + m17_mod_dibits / m17_mod_carrier (m17_modulate.cpp:22-92) at 10 samples per symbol."""
+
+    def __init__(self):
+        self.buf = np.zeros(L().m17o_sizeof_mod(), np.uint8)
+        L().m17o_mod_init(vp(self.buf))
+
+    def modulate(self, dibits, stages=False):
+        """dibits uint8 (0..3, 255 = carrier) -> iq int16 [10 n, 2] (, sums float32 [10 n], phases float32 [10 n])"""
+        dibits = np.ascontiguousarray(dibits, np.uint8)
+        n = len(dibits)
+        iq = np.zeros((10 * n, 2), np.int16)
+        sums = np.zeros(10 * n, np.float32) if stages else None
+        ph = np.zeros(10 * n, np.float32) if stages else None
+        assert L().m17o_modulate(vp(self.buf), vp(dibits), n, vp(iq), vp(sums) if stages else None, vp(ph) if stages else None) == 10 * n
+        return (iq, sums, ph) if stages else iq
+
+
+def tx_stream_schedule(lsf, payloads, n_stream_frames, nslots):
+    """The dibit schedule of one channel as the reference's transmit thread sends a voice stream
+    (m17_tx_rx.cpp:95-98: carrier, two preambles, link setup; then stream frames; m17_send_eot), repeated:
+    uint8 [nslots, 192].  payloads [>= frames sent][16]; the LICH counter and FN restart with every transmission
+    (m17_send_link_setup_frame, m17_tx_routines.cpp:273-275)."""
+    out = np.zeros((nslots, 192), np.uint8)
+    period = 5 + n_stream_frames
+    sent = 0
+    for g in range(nslots):
+        slot = g % period
+        if slot == 0:
+            out[g] = 255
+        elif slot <= 2:
+            out[g] = tx_preamble()
+        elif slot == 3:
+            out[g] = tx_lsf_frame(lsf)
+        elif slot == 4 + n_stream_frames:
+            out[g] = tx_eot()
+        else:
+            f = slot - 4
+            out[g] = tx_stream_frame(lsf, f % 6, f, payloads[sent % len(payloads)])
+            sent += 1
+    return out

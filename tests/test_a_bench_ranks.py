@@ -169,7 +169,7 @@ def test_capi_fanout_entries_with_a_one_rank_rccl_communicator():
         pall = torch.zeros_like(packed)
         oall = torch.full((Cn + 1,), -1, dtype=torch.int32, device="cuda")
         totals = (C.c_int32 * 1)()
-        rc = lib.m17gpu_shard_gather_packed(rx._ctx, comm, 0, 1, 0, p(packed), p(offs), Cn, p(pall), int(pall.shape[0]), p(oall), totals, st)
+        rc = lib.m17gpu_shard_gather_packed(rx._ctx, comm, 0, 1, 0, p(packed), int(packed.shape[0]), p(offs), Cn, p(pall), int(pall.shape[0]), p(oall), totals, st)
         assert rc == 0, lib.m17gpu_last_error()
         torch.cuda.synchronize()
         want_offs = np.concatenate([[0], np.cumsum(ref["counts"])]).astype(np.int32)
@@ -186,7 +186,11 @@ def test_capi_fanout_entries_with_a_one_rank_rccl_communicator():
         for c in range(Cn):
             assert ur[c, :ref["counts"][c]].tobytes() == ref["recs"][c, :ref["counts"][c]].tobytes() and not ur[c, ref["counts"][c]:].view(np.uint8).any()
         # a destination too small for the step's records is refused, not overrun
-        assert lib.m17gpu_shard_gather_packed(rx._ctx, comm, 0, 1, 0, p(packed), p(offs), Cn, p(pall), 3, p(oall), None, st) != 0
+        assert lib.m17gpu_shard_gather_packed(rx._ctx, comm, 0, 1, 0, p(packed), int(packed.shape[0]), p(offs), Cn, p(pall), 3, p(oall), None, st) == m.ERR_ARG
+        # ... and so is a source buffer smaller than what m17gpu_pack_records counted (rows beyond its capacity were never written)
+        assert lib.m17gpu_shard_gather_packed(rx._ctx, comm, 0, 1, 0, p(packed), 3, p(offs), Cn, p(pall), int(pall.shape[0]), p(oall), None, st) == m.ERR_ARG
+        # the refusals left the communicator usable
+        assert lib.m17gpu_shard_gather_packed(rx._ctx, comm, 0, 1, 0, p(packed), int(packed.shape[0]), p(offs), Cn, p(pall), int(pall.shape[0]), p(oall), totals, st) == 0
         # a context that does not hold the rank's range is refused
         assert lib.m17gpu_shard_scatter_iq(rx._ctx, comm, 0, 2, 0, p(full), Cn, nblk, p(mine), st) != 0
         rx.close()

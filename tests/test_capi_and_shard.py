@@ -31,6 +31,17 @@ def test_library_exports_every_declared_symbol():
     assert C.sizeof(_lib.Rec) == 64
 
 
+def test_library_exports_nothing_the_header_does_not_declare():
+    """The shipped library's dynamic symbols in the m17gpu_ / m17gen_ name space are exactly the header's: experiments and
+    measurement hooks belong in the instrumented build (make stamps), not in libm17gpu.so."""
+    import subprocess
+    from m17_sdr_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if re.match(r".* [TW] m17g(pu|en)_", ln)})
+    declared = _declared_symbols()
+    assert exported == declared, sorted(set(exported) ^ set(declared))
+
+
 def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
     """The drop-in boundary is a C ABI: include/m17gpu.h must compile as C99 (no C++, no torch, no HIP or RCCL types) and a
     C program must link against libm17gpu.so with nothing but that header -- here one that touches only host-side entries
@@ -147,6 +158,24 @@ if rank == 0:
     for c in range(C):
         assert pa[want_offs[c]:want_offs[c + 1]].numpy().tobytes() == whole["recs"][c, :whole["counts"][c]].tobytes()
     print("PACKED_OK", pa.shape[0] * 64, "bytes of records against", gr.numel(), "unpacked")
+# a rank whose packed buffer is smaller than its step's records (pack_records wrote no row beyond it): every rank is
+# told in the one exchange all of them take part in, every rank raises, none is left in a send or a receive
+short = rank == world - 1 and len(rows) > 1
+try:
+    gather_packed(packed[:1] if short else packed, offs, dst=0)
+    refused = False
+except ValueError as e:
+    refused = "refused on every rank" in str(e)
+flags = [None] * world
+dist.all_gather_object(flags, (refused, len(rows)))
+if flags[world - 1][1] > 1:
+    assert all(f[0] for f in flags), flags
+    pa2, oa2, _ = gather_packed(packed, offs, dst=0)            # and the group is as good as new
+    if rank == 0:
+        assert torch.equal(pa2, pa) and torch.equal(oa2, oa)
+        print("REFUSAL_OK")
+elif rank == 0:
+    print("REFUSAL_OK (last rank holds too few records to come up short)")
 dist.destroy_process_group()
 """
 
@@ -164,7 +193,7 @@ def test_scatter_gather_over_gloo(tmp_path, world, channels, port):
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert "GATHER_OK" in outs[0] and "PACKED_OK" in outs[0]
+    assert "GATHER_OK" in outs[0] and "PACKED_OK" in outs[0] and "REFUSAL_OK" in outs[0], outs
 
 
 def test_net_frame_format():

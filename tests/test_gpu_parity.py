@@ -162,7 +162,7 @@ def test_exact_arithmetic_selftest():
 
 
 @pytest.mark.parametrize("options", [
-    {"sync_impl": 6}, {"sync_impl": 7}, {"fe_impl": 1}, {"fe_impl": 2}, {"fe_impl": 3}, {"fir_impl": 2}, {"fir_impl": 1, "sync_impl": 7}])
+    {"sync_impl": 6}, {"sync_impl": 7}, {"fe_impl": 1}, {"fe_impl": 2}, {"fe_impl": 3}, {"fir_impl": 2}, {"fir_impl": 3}, {"fir_impl": 4}, {"fir_impl": 1, "sync_impl": 7}])
 def test_every_kernel_variant_is_bit_exact(options):
     _rx_compare(C=40, nblk=22, mode=1, ebn0=200.0, nsf=12, options=options)
     _rx_compare(C=40, nblk=9, mode=1, ebn0=9.0, nsf=5, calls=3, options=options)
@@ -213,7 +213,7 @@ def test_config2_1024_channels_front_end_bit_exact():
     _rx_compare(C=1024, nblk=10, mode=0, ebn0=7.0, nsf=6)
 
 
-@pytest.mark.parametrize("ebn0,options", [(4.0, {}), (8.0, {}), (12.0, {}), (10.0, {"fir_impl": 2}), (10.0, {"fe_impl": 3})])
+@pytest.mark.parametrize("ebn0,options", [(4.0, {}), (8.0, {}), (12.0, {}), (10.0, {"fir_impl": 2}), (10.0, {"fe_impl": 3}), (10.0, {"fir_impl": 3})])
 def test_config4_16384_channels_awgn_bit_exact(ebn0, options):
     """BASELINE configs[3] at its real size: 16,384 channels on one GPU, band-limited AWGN, signal from
     the device generator (every channel distinct), DEFAULT options -- so the kernels the bench runs at this size
@@ -501,11 +501,11 @@ def test_set_option_rejects_unknown_and_out_of_range_values():
     import m17_sdr_amd as m
     rx = m.Receiver(2, 2)
     for name, value in (("fe_impl", 101), ("fe_impl", 107), ("fe_impl", -1), ("fe_impl", 4), ("sync_impl", 2),
-                        ("sync_impl", 5), ("sync_impl", 1), ("sync_impl", 4), ("fir_impl", 3), ("fir_impl", -1), ("overlap_chunks", 2), ("fe_waves_per_cu", 8), ("lanes_per_channel", 16),
+                        ("sync_impl", 5), ("sync_impl", 1), ("sync_impl", 4), ("fir_impl", 5), ("fir_impl", -1), ("overlap_chunks", 2), ("fe_waves_per_cu", 8), ("lanes_per_channel", 16),
                         ("decode_impl", 0), ("no_such_option", 1)):
         with pytest.raises(RuntimeError):
             rx.set_option(name, value)
-    for name, value in (("fe_impl", 0), ("fe_impl", 1), ("fe_impl", 2), ("fe_impl", 3), ("sync_impl", 0), ("sync_impl", 6), ("sync_impl", 7), ("fir_impl", 0), ("fir_impl", 1), ("fir_impl", 2)):
+    for name, value in (("fe_impl", 0), ("fe_impl", 1), ("fe_impl", 2), ("fe_impl", 3), ("sync_impl", 0), ("sync_impl", 6), ("sync_impl", 7), ("fir_impl", 0), ("fir_impl", 1), ("fir_impl", 2), ("fir_impl", 3), ("fir_impl", 4)):
         rx.set_option(name, value)
     rx.close()
 
@@ -596,27 +596,79 @@ def test_timing_loop_wraps_both_ways_and_first_tick_slip():
     rx.close()
 
 
-@pytest.mark.parametrize("ebn0,cutoff", [(200.0, 0.0), (9.0, 0.0), (8.0, 6250.0)])
-def test_gpu_signal_source_matches_host_generator(ebn0, cutoff):
-    """the device generator makes the host generator's signal.  Frame bits, filter sums and
-    phases are the same arithmetic and identical; the final cosf/sinf (single precision, as the reference's
-    overload resolution selects, m17_modulate.cpp:25-26) come from two math libraries, glibc and the device
-    library, which differ in the last place now and then: an IQ sample may differ by ONE LSB, on about one
-    sample in 10^4.  What each receiver decodes from its own copy is compared bit for bit."""
+def test_gpu_signal_source_matches_the_oracle_transmitter():
+    """the device generator against the ORACLE's transmitter (oracle/m17_oracle.c: frame builders of
+    m17_tx_routines.cpp:24-255, modulator of m17_modulate.cpp:22-92), stage by stage: the dibits of every slot and the
+    modulator's phase accumulator after every sample bit for bit; the IQ samples -- cosf / sinf of that phase in single
+    precision, as the reference's overload resolution selects (m17_modulate.cpp:25-26) -- from two math libraries, glibc
+    in the oracle and the device library here, which differ in the last place now and then: one LSB on about one sample
+    in 10^4."""
     torch = _torch()
     import m17_sdr_amd as m
-    C, nblk, nsf = 37, 14, 9
-    host = m.generate_batch(C, nblk, n_stream_frames=nsf, ebn0_db=ebn0, noise_cutoff_hz=cutoff, first_channel=5)
+    from tests.test_oracle_tx import channel_delay
+    C, nblk, nsf, first = 23, 14, 9, 5
     rx = m.Receiver(C, nblk)
-    dev = rx.gen_batch(nblk, n_stream_frames=nsf, ebn0_db=ebn0, noise_cutoff_hz=cutoff, first_channel=5)
+    dev = rx.gen_batch(nblk, n_stream_frames=nsf, first_channel=first, stages=True)
     torch.cuda.synchronize()
-    giq = dev["iq"].cpu().numpy()
-    diff = np.abs(giq.astype(np.int32) - host["iq"].astype(np.int32))
-    assert diff.max() <= 1, int(diff.max())
-    assert (diff != 0).mean() < 1e-3, float((diff != 0).mean())
-    np.testing.assert_array_equal(dev["lsf"].cpu().numpy(), host["lsf"])
-    np.testing.assert_array_equal(dev["nframes"].cpu().numpy(), host["nframes"])
-    np.testing.assert_array_equal(dev["payload"].cpu().numpy(), host["payload"])
+    giq, lsf, pay = dev["iq"].cpu().numpy(), dev["lsf"].cpu().numpy(), dev["payload"].cpu().numpy()
+    dib, ph, nfr = dev["dibits"].cpu().numpy(), dev["phase"].cpu().numpy(), dev["nframes"].cpu().numpy()
+    want_n = nblk * 1920
+    ndiff = 0
+    for c in range(C):
+        assert oracle.L().m17o_crc(oracle.vp(np.ascontiguousarray(lsf[c])), 30) == 0
+        delay = channel_delay(first + c)
+        sched = oracle.tx_stream_schedule(lsf[c], pay[c], nsf, nblk + 1)
+        np.testing.assert_array_equal(dib[c], sched)
+        iq, _, phases = oracle.Modulator().modulate(sched.reshape(-1), stages=True)
+        wp = np.zeros(want_n, np.float32)
+        wp[delay:] = phases[:want_n - delay]
+        np.testing.assert_array_equal(ph[c].view(np.uint32), wp.view(np.uint32))
+        wiq = np.empty((want_n, 2), np.int16)
+        wiq[:delay] = (0x3FFF, 0)
+        wiq[delay:] = iq[:want_n - delay]
+        d = np.abs(giq[c].reshape(-1, 2).astype(np.int32) - wiq.astype(np.int32))
+        assert d.max() <= 1, int(d.max())
+        ndiff += int((d != 0).sum())
+        period = 5 + nsf
+        assert nfr[c] == sum(1 for g in range(nblk + 1) if 4 <= g % period < 4 + nsf and delay + g * 1920 < want_n)
+    assert ndiff < 1e-3 * C * want_n * 2, ndiff
+    rx.close()
+
+
+@pytest.mark.parametrize("ebn0,cutoff", [(9.0, 0.0), (8.0, 6250.0)])
+def test_gpu_signal_source_noise_level_and_decode_parity(ebn0, cutoff):
+    """The generator's AWGN (not part of the reference: SURVEY 8d adds it) against its specification -- complex noise
+    of variance N0 = Es / (2 Eb/N0) per 48 kHz sample on top of the oracle transmitter's signal, optionally through a
+    unity-DC-gain 63-tap low-pass -- and what the receiver decodes from it against the oracle on the same samples."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    from tests.test_oracle_tx import channel_delay
+    C, nblk, nsf, first = 24, 14, 9, 3
+    rx = m.Receiver(C, nblk)
+    dev = rx.gen_batch(nblk, n_stream_frames=nsf, ebn0_db=ebn0, noise_cutoff_hz=cutoff, first_channel=first)
+    torch.cuda.synchronize()
+    giq, lsf, pay = dev["iq"].cpu().numpy(), dev["lsf"].cpu().numpy(), dev["payload"].cpu().numpy()
+    want_n = nblk * 1920
+    sigma = np.sqrt(16383.0 ** 2 * 10 / (2.0 * 2.0 * 10 ** (ebn0 / 10.0)))      # per component
+    noise = []
+    for c in range(C):
+        delay = channel_delay(first + c)
+        iq = oracle.Modulator().modulate(oracle.tx_stream_schedule(lsf[c], pay[c], nsf, nblk + 1).reshape(-1))
+        clean = np.empty((want_n, 2), np.float64)
+        clean[:delay] = (0x3FFF, 0)
+        clean[delay:] = iq[:want_n - delay]
+        noise.append(giq[c].reshape(-1, 2).astype(np.float64) - clean)
+    noise = np.concatenate(noise)
+    assert abs(noise.mean()) < 0.02 * sigma
+    if cutoff == 0.0:
+        assert abs(noise.std() / sigma - 1.0) < 0.02, (noise.std(), sigma)
+    else:
+        # a low-pass of one-sided cutoff fc keeps about 2 fc / 48 kHz of a white spectrum's power (Hamming window: a little less)
+        frac = noise.var() / sigma ** 2
+        assert 0.8 * (2 * cutoff / 48000.0) < frac < 1.1 * (2 * cutoff / 48000.0), frac
+        spec = np.abs(np.fft.fft(noise[:1 << 16, 0] + 1j * noise[:1 << 16, 1])) ** 2
+        f = np.abs(np.fft.fftfreq(1 << 16, 1 / 48000.0))
+        assert spec[f > 2.0 * cutoff].mean() < 1e-2 * spec[f < 0.5 * cutoff].mean()
     out = rx.rx_blocks(dev["iq"], 1, rx.alloc_outputs(nblk))
     torch.cuda.synchronize()
     ref = oracle.Channels(C).rx_blocks(giq, mode=1, want_syms=False)        # the oracle on the SAME (device-made) IQ
@@ -625,14 +677,6 @@ def test_gpu_signal_source_matches_host_generator(ebn0, cutoff):
     recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
     for c in range(C):
         assert recs[c, :counts[c]].tobytes() == ref["recs"][c, :counts[c]].tobytes()
-    if ebn0 >= 100.0:
-        # noiseless: one LSB in 10^4 samples must not change what is decoded from the host-made signal either
-        href = oracle.Channels(C).rx_blocks(host["iq"], mode=1, want_syms=False)
-        for c in range(C):
-            sel = ref["recs"][c, :counts[c]]
-            hsel = href["recs"][c, :href["counts"][c]]
-            assert [bytes(r["data"]) for r in sel if r["flags"] & m.F_DELIVERED] == \
-                   [bytes(r["data"]) for r in hsel if r["flags"] & m.F_DELIVERED]
     rx.close()
 
 
@@ -911,13 +955,17 @@ def test_squelched_channels_do_not_slow_the_timing_stage():
         for _ in range(2):
             rx.rx_blocks(iq, 1, out)
         torch.cuda.synchronize()
-        rx.set_profiling(True)
-        for _ in range(4):
-            rx.rx_blocks(iq, 1, out)
-        torch.cuda.synchronize()
-        times[name] = rx.kernel_ms()[0][1]
+        best = None
+        for _ in range(5):                                # the box is shared: the fastest of five short runs per case
+            rx.set_profiling(True)
+            for _ in range(3):
+                rx.rx_blocks(iq, 1, out)
+            torch.cuda.synchronize()
+            t = rx.kernel_ms()[0][1]
+            best = t if best is None else min(best, t)
+        times[name] = best
         rx.close()
-    # a guard against the 15x regression only (the box is shared: no tight ratio here; the measured figures are kept by
-    # scripts/exp_dead_channels.py under profiles/)
-    assert times["zeros"] < 6.0 * times["signal"], times
-    assert times["carrier"] < 6.0 * times["signal"], times
+    # measured: dead channels cost 0.6-1.3 x a live one's time (scripts/exp_dead_channels.py, profiles/); 15 x before the
+    # hunt pass had its sign-less clause
+    assert times["zeros"] < 3.0 * times["signal"], times
+    assert times["carrier"] < 3.0 * times["signal"], times
