@@ -256,7 +256,7 @@ void k_rx_fused(const uint4 *__restrict__ iq,              // [C][nblk][480] uin
 // slots, and the waves of a SIMD drift apart, so the two phases overlap on the chip -- which two launches cannot do
 // (DESIGN.md section 6).  LDS: the front end's two tiles and the timing loop's WvChan share one region.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int RC_WAVES = 8;                      // two waves per SIMD and workgroup: one of each half (STAGGER)
+constexpr int RC_WAVES = 4;
 constexpr int RC_LDS = 10240;                  // per wave: >= 2 x 16 x FQ_STRIDE x 4 = 8,704 B and >= sizeof(WvChan); a multiple of 2 KB (ring alignment)
 static_assert(RC_LDS >= 2 * 16 * FQ_STRIDE * 4 && RC_LDS >= (int)sizeof(WvChan) && RC_LDS % 2048 == 0, "k_rx_chan LDS layout");
 
@@ -270,10 +270,15 @@ __device__ __forceinline__ int rc_lane()
     return l;
 }
 
-// STAGGER: the upper half of a workgroup's waves runs its front-end phases one group AHEAD of its timing phases
-// (F0 F1 T0 F2 T1 ... T_last instead of F0 T0 F1 T1 ...): the two halves sit on the same SIMDs, and waves that start
-// together would otherwise all wait on memory together and then all want issue slots together.
-template <int STAGGER>
+// Measured alternatives (round 5, profiles/r05_rx_chan_variants.txt), none kept: several channels per wave so that twelve-block
+// calls fill whole tiles (4 channels = 48 rows = 3 tiles: 4,096 waves, one generation, every wave in the same phase at the
+// same time -- no faster than two kernels); the workgroup's waves sharing the tiles of its channels behind a barrier (the
+// barrier puts the two waves of a SIMD into the same phase: +3 % at sixteen blocks); the upper half of a workgroup's
+// waves running its tiles one group ahead (-1..2 % at 32 and 48 blocks, nothing at 16).
+#ifdef M17_STAMPS
+__device__ unsigned long long g_rc_stamps[16384][4];          // per channel: ticks in front-end tiles, in timing phases, realtime in / out
+#endif
+template <int HALF>
 __global__ __launch_bounds__(64 * RC_WAVES, 4)
 void k_rx_chan(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float *__restrict__ disc, float *__restrict__ offs,
                int C, int nblk, int mode, m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
@@ -287,24 +292,91 @@ void k_rx_chan(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float *
     float *otile = reinterpret_cast<float *>(lds[wave] + 16 * FQ_STRIDE * 4);
     WvChan &wc = *reinterpret_cast<WvChan *>(lds[wave]);
     const int row0 = chan * nblk, row_end = row0 + nblk;      // the channel's rows of the [C * nblk] row space
-    const bool ahead = STAGGER && wave >= RC_WAVES / 2;
-    auto front = [&](int b0) {
+#ifdef M17_STAMPS
+    unsigned long long t_fe = 0, t_tm = 0, t_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt_in = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int b0 = 0; b0 < nblk; b0 += 16) {
         // rows b0 .. b0 + 15 of this channel (rows past its last block are computed on its last row and never stored)
         frontend_d_tile(iq, st, disc, offs, nblk, row_end, 1, row0 + b0, tile, otile, rc_lane());
         // the rows must be in memory before this wave reads them back (same wave, same addresses: its own stores are
         // ordered behind its vmcnt; the loads of the timing phase are non-temporal, served by L2)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_sync();
-    };
-    if (ahead) front(0);
-    for (int b0 = 0; b0 < nblk; b0 += 16) {
-        if (!ahead) front(b0);
-        else if (b0 + 16 < nblk) front(b0 + 16);
-        sync_wave_channel(disc, offs, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, min(16, nblk - b0),
-                          chan, wc, wave, rc_lane());
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // channel state out before the next group reads it
+#ifdef M17_STAMPS
+        { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fe += now - t_last; t_last = now; }
+#endif
+        sync_wave_channel<HALF>(disc, offs, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, min(16, nblk - b0),
+                                chan, wc, wave, rc_lane());
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // channel state out before the next group reads it
         wave_lds_sync();
+#ifdef M17_STAMPS
+        { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_tm += now - t_last; t_last = now; }
+#endif
     }
+#ifdef M17_STAMPS
+    if (chan < 16384 && lane_id() == 0) {
+        g_rc_stamps[chan][0] = t_fe; g_rc_stamps[chan][1] = t_tm; g_rc_stamps[chan][2] = rt_in; g_rc_stamps[chan][3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
+
+// k_rx_chan6 (round 5; option fir_impl 4): k_rx_chan built for SIX waves per SIMD -- frontend_lite_tile (32-sample chunks,
+// ~60 VGPRs, 4.6 KB of LDS) and the timing loop with taps and window through half the registers (sync_wave_channel<1>):
+// the stage is bound by instruction issue at the rate ONE wave can issue (a wave never issues faster than every ~5 cycles,
+// profiles/r03_issue_rates_gfx950.txt), so what a SIMD gets done grows with the waves it holds: 4 -> 6 waves is +15..20 %.
+constexpr int RC6_LDS = 6144;                  // per wave: the two 2,304-byte tiles / the timing loop's WvChan (4 KB); a multiple of 2 KB (ring alignment)
+static_assert(RC6_LDS >= 2 * FL_TILE_BYTES && RC6_LDS >= (int)sizeof(WvChan) && RC6_LDS % 2048 == 0, "k_rx_chan6 LDS layout");
+template <int HALF, int OCC, bool DEEP>
+__global__ __launch_bounds__(64 * RC_WAVES, OCC)
+void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float *__restrict__ disc, float *__restrict__ offs,
+                int C, int nblk, int mode, m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
+                float *__restrict__ syms, int32_t *__restrict__ nsyms, float *__restrict__ fsym, int nslots)
+{
+    __shared__ __attribute__((aligned(4096))) unsigned char lds[RC_WAVES][RC6_LDS];
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int chan = (int)blockIdx.x * RC_WAVES + wave;
+    if (chan >= C) return;
+    uint32_t *tile = reinterpret_cast<uint32_t *>(lds[wave]);
+    float *otile = reinterpret_cast<float *>(lds[wave] + FL_TILE_BYTES);
+    WvChan &wc = *reinterpret_cast<WvChan *>(lds[wave]);
+    const int row0 = chan * nblk;
+#ifdef M17_STAMPS
+    unsigned long long t_fe = 0, t_tm = 0, t_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt_in = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int b0 = 0; b0 < nblk; b0 += 16) {
+        const int bc = min(16, nblk - b0);
+        // where the group's sixteen rows travel: the channel's own rows of the workspace, or (EXPERIMENT, nslots > 0) a
+        // compact region of nslots x 16 rows that stays in the cache levels -- row r of the group at slot * 16 + r
+        float *dw = disc, *ow = offs;
+        if (nslots > 0) {
+            const int slot = chan % nslots;
+            dw = disc + ((size_t)slot * 16 - (size_t)(row0 + b0)) * kDiscOut;
+            ow = offs + ((size_t)slot * 16 - (size_t)(row0 + b0));
+        }
+        // rows b0 .. b0 + 15 of this channel (rows past its last block are computed on its last row and never stored)
+        frontend_lite_tile<DEEP>(iq, st, dw, ow, nblk, 1,
+                                 [&](int i, bool &valid) { valid = i < bc; return row0 + b0 + (valid ? i : bc - 1); }, tile, otile, rc_lane());
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the rows are in memory before this wave reads them back
+        wave_lds_sync();
+#ifdef M17_STAMPS
+        { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fe += now - t_last; t_last = now; }
+#endif
+        sync_wave_channel<HALF>(dw, ow, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, bc,
+                                chan, wc, wave, rc_lane());
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // channel state out before the next group reads it
+        wave_lds_sync();
+#ifdef M17_STAMPS
+        { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_tm += now - t_last; t_last = now; }
+#endif
+    }
+#ifdef M17_STAMPS
+    if (chan < 16384 && lane_id() == 0) {
+        g_rc_stamps[chan][0] = t_fe; g_rc_stamps[chan][1] = t_tm; g_rc_stamps[chan][2] = rt_in; g_rc_stamps[chan][3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 } // namespace m17dev

@@ -501,20 +501,66 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
 // quarter of them.  The picks (sample position % 5 == 4) are at most four of a lane's sixteen values: entries e0, e0+5,
 // e0+10 (and 15 when e0 == 0) with e0 = 4 - (lane's first position % 5), written straight into the output tile.
 // ---------------------------------------------------------------------------
+// dsp_short_to_float + dsp_limit (m17_dsp.cpp:136-141,412-419) of N samples (N even): the exact-arithmetic sequences of
+// s16_to_float / sqrt_rn_normal / rcp_rn_normal on two-vectors (same IEEE operations in the same order per sample, so the
+// same bits: m17gpu_selftest proves the scalar forms, test_stage_frontend compares this one with the oracle), every stage
+// over all N samples before the next, so that no instruction waits on the one in front of it.
+constexpr int FE_GROUP = 8;            // samples per fe_convert call in the tile kernels: two independent pair chains fill each other's wait states
+template <int N>
+__device__ __forceinline__ void fe_convert(const uint32_t *w, v2f *z)
+{
+    const v2f chi = {0x1.f75104p-16f, 0x1.f75104p-16f}, clo = {0x1.aaa3aep-41f, 0x1.aaa3aep-41f}, half = {0.5f, 0.5f}, one = {1.0f, 1.0f};
+    v2f x[N], q[N];
+    float a[N], r[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) x[e] = (v2f){(float)(int)(short)(w[e] & 0xFFFF), (float)((int)w[e] >> 16)};
+#pragma unroll
+    for (int e = 0; e < N; ++e) q[e] = x[e] * clo;
+#pragma unroll
+    for (int e = 0; e < N; ++e) x[e] = __builtin_elementwise_fma(x[e], chi, q[e]);          // s16_to_float
+#pragma unroll
+    for (int e = 0; e < N; ++e) q[e] = x[e] * x[e];
+    // re * re + im * im as a plain add (left to the compiler: three moves and a packed add per sample pair)
+#pragma unroll
+    for (int e = 0; e < N; ++e) asm("v_add_f32 %0, %1, %2" : "=v"(a[e]) : "v"(q[e].x), "v"(q[e].y));
+#pragma unroll
+    for (int e = 0; e < N; ++e) r[e] = __builtin_amdgcn_rsqf(a[e]);
+    v2f A[N / 2], Q[N / 2], Y[N / 2], R[N / 2], M[N / 2], R0[N / 2], E[N / 2], G[N / 2];
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) { A[p] = (v2f){a[2 * p], a[2 * p + 1]}; Q[p] = (v2f){r[2 * p], r[2 * p + 1]}; }
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) Y[p] = A[p] * Q[p];                                         // sqrt_rn_normal
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) Q[p] = Q[p] * half;
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) R[p] = __builtin_elementwise_fma(-Y[p], Y[p], A[p]);
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) M[p] = __builtin_elementwise_fma(R[p], Q[p], Y[p]);
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) R0[p] = (v2f){__builtin_amdgcn_rcpf(M[p].x), __builtin_amdgcn_rcpf(M[p].y)};
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) E[p] = __builtin_elementwise_fma(-M[p], R0[p], one);        // rcp_rn_normal
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) G[p] = __builtin_elementwise_fma(E[p], R0[p], R0[p]);
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) { z[2 * p] = x[2 * p] * (v2f){G[p].x, G[p].x}; z[2 * p + 1] = x[2 * p + 1] * (v2f){G[p].y, G[p].y}; }
+}
+
 __device__ __forceinline__ float dpp_quad_left(float v)       // quad lanes (0,1,2,3) read lanes (0,0,1,2)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x90, 0xF, 0xF, true));
 }
-// one tile = the 16 (channel, block) rows cb0 .. cb0 + 15; my / myo: the wave's raw and output tiles in LDS (16 x FQ_STRIDE dwords each)
-__device__ __forceinline__ void frontend_d_tile(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
-                                                float *__restrict__ disc_raw, float *__restrict__ offs,
-                                                int nblk, int total, int update_state, const int cb0, uint32_t *my, float *myo,
-                                                const int lane = lane_id())
+// one tile = 16 rows; my / myo: the wave's raw and output tiles in LDS (16 x FQ_STRIDE dwords each).  Which (channel,
+// block) row tile row i is, is the caller's: rowmap(i, valid) returns the row's index cb in the [C * nblk] row space
+// (channel = cb / nblk) and whether its results are to be stored (rows past the end compute on a valid row's input).
+template <class RowMap>
+__device__ __forceinline__ void frontend_tile(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
+                                              float *__restrict__ disc_raw, float *__restrict__ offs,
+                                              int nblk, int update_state, RowMap rowmap, uint32_t *my, float *myo, const int lane)
 {
     const int cbl = lane >> 2, sub = lane & 3;
-    if (cb0 >= total) return;
-    const bool valid = (cb0 + cbl) < total;
-    const int cb = valid ? cb0 + cbl : total - 1;
+    bool valid;
+    const int cb = rowmap(cbl, valid);
     const int chan = cb / nblk, blk = cb - chan * nblk;
 
     float c0re, c0im, c1re, c1im;
@@ -533,7 +579,8 @@ __device__ __forceinline__ void frontend_d_tile(const uint4 *__restrict__ iq, Ch
 
     const int lr = lane >> 4, c16 = lane & 15;
     auto row_ptr = [&](int j) {
-        int row = cb0 + j * 4 + lr; row = row < total ? row : total - 1;
+        bool v_;
+        const int row = rowmap(j * 4 + lr, v_);
         return iq + (size_t)row * (kBlockSamples / 4) + c16;
     };
     const uint4 *g0 = row_ptr(0), *g1 = row_ptr(1), *g2 = row_ptr(2), *g3 = row_ptr(3);
@@ -568,29 +615,12 @@ __device__ __forceinline__ void frontend_d_tile(const uint4 *__restrict__ iq, Ch
             w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
         }
         wave_lds_sync();                                       // every lane holds its samples: the tile is free
-        // conversion + limiter on (re, im) pairs, the exact-arithmetic sequences of s16_to_float / sqrt_rn_normal /
-        // rcp_rn_normal written on two-vectors so that they issue as packed fp32 (same IEEE operations, same order):
-        // per sample pair the six fix-up operations of the limiter are three packed ones
+        // conversion + limiter, eight samples at a time and STAGE BY STAGE (fe_convert, FE_GROUP samples at a time): written sample by sample the
+        // compiler emits each sample pair's eleven dependent steps back to back with an s_nop behind nearly every one
+        // (417 s_nop in this kernel's five-chunk body, round 5)
         v2f z[16];
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            v2f x0 = {(float)(int)(short)(w[e] & 0xFFFF), (float)((int)w[e] >> 16)};
-            v2f x1 = {(float)(int)(short)(w[e + 1] & 0xFFFF), (float)((int)w[e + 1] >> 16)};
-            const v2f chi = {0x1.f75104p-16f, 0x1.f75104p-16f}, clo = {0x1.aaa3aep-41f, 0x1.aaa3aep-41f};
-            x0 = __builtin_elementwise_fma(x0, chi, x0 * clo);            // s16_to_float
-            x1 = __builtin_elementwise_fma(x1, chi, x1 * clo);
-            const v2f q0 = x0 * x0, q1 = x1 * x1;
-            const v2f a = {q0.x + q0.y, q1.x + q1.y};                      // re * re + im * im of the two samples
-            const v2f q = {__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)};
-            const v2f y0 = a * q;                                          // sqrt_rn_normal
-            const v2f r = __builtin_elementwise_fma(-y0, y0, a);
-            const v2f m = __builtin_elementwise_fma(r, q * (v2f){0.5f, 0.5f}, y0);
-            const v2f r0 = {__builtin_amdgcn_rcpf(m.x), __builtin_amdgcn_rcpf(m.y)};
-            const v2f er = __builtin_elementwise_fma(-m, r0, (v2f){1.0f, 1.0f});     // rcp_rn_normal
-            const v2f g = __builtin_elementwise_fma(er, r0, r0);
-            z[e] = x0 * (v2f){g.x, g.x};
-            z[e + 1] = x1 * (v2f){g.y, g.y};
-        }
+        for (int e = 0; e < 16; e += FE_GROUP) fe_convert<FE_GROUP>(&w[e], &z[e]);
         v2f p0 = {dpp_row_shr1(z[15].x), dpp_row_shr1(z[15].y)};          // sample -1 of this lane's run
         v2f p1 = {dpp_row_shr1(z[14].x), dpp_row_shr1(z[14].y)};          // sample -2
         if (sub0) { p0 = (v2f){c0re, c0im}; p1 = (v2f){c1re, c1im}; }
@@ -661,6 +691,188 @@ __device__ __forceinline__ void frontend_d_tile(const uint4 *__restrict__ iq, Ch
         }
     }
 }
+// the 16 consecutive rows cb0 .. cb0 + 15 of the row space (rows from `total` on are not stored)
+__device__ __forceinline__ void frontend_d_tile(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
+                                                float *__restrict__ disc_raw, float *__restrict__ offs,
+                                                int nblk, int total, int update_state, const int cb0, uint32_t *my, float *myo,
+                                                const int lane = lane_id())
+{
+    if (cb0 >= total) return;
+    frontend_tile(iq, st, disc_raw, offs, nblk, update_state,
+                  [&](int i, bool &valid) { valid = cb0 + i < total; return valid ? cb0 + i : total - 1; }, my, myo, lane);
+}
+// rows g0 .. g0 + 15 of a GROUP: blocks b0 .. b0 + bc - 1 of the channels chan0, chan0 + 1, ... numbered channel by
+// channel (group row g = channel g / bc, block b0 + g % bc); `grows` rows in the group
+__device__ __forceinline__ void frontend_g_tile(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
+                                                float *__restrict__ disc_raw, float *__restrict__ offs,
+                                                int nblk, int chan0, int b0, int bc, int grows, const int g0, uint32_t *my, float *myo,
+                                                const int lane)
+{
+    frontend_tile(iq, st, disc_raw, offs, nblk, 1,
+                  [&](int i, bool &valid) {
+                      valid = g0 + i < grows;
+                      const int g = valid ? g0 + i : grows - 1;
+                      const int c = g / bc;
+                      return (chan0 + c) * nblk + b0 + (g - c * bc);
+                  }, my, myo, lane);
+}
+// ---------------------------------------------------------------------------
+// frontend_lite_tile (round 5): the tile of frontend_tile at HALF the chunk -- 32 samples per row and chunk, eight per
+// lane -- for the kernels that have to share a SIMD with five other waves: ~60 live VGPRs instead of ~106 and 4.6 KB of
+// LDS instead of 8.7 (a raw tile and an output tile of 16 x 36 dwords; 32 outputs per row = 160 samples = five chunks
+// between two stores of 128 B per row).  Same arithmetic, same order: the DC chain walks the quad in four steps of eight
+// adds, the picks (sample position % 5 == 4) are the lane's entries e0 and e0 + 5 with e0 = 4 - (first position % 5).
+// ---------------------------------------------------------------------------
+constexpr int FL_CHUNK = 32, FL_STRIDE = 36, FL_NCHUNK = kBlockSamples / FL_CHUNK;    // 60 chunks per block
+constexpr int FL_TILE_BYTES = 16 * FL_STRIDE * 4;                                      // 2,304 B each, raw and output
+// DEEP: five chunks (10 KB per wave) of input in flight instead of one -- a wave that shares its SIMD with waves in the
+// timing phase is one of few that stream, and with one chunk in flight each they do not cover the memory latency
+template <bool DEEP = false, class RowMap>
+__device__ __forceinline__ void frontend_lite_tile(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
+                                                   float *__restrict__ disc_raw, float *__restrict__ offs,
+                                                   int nblk, int update_state, RowMap rowmap, uint32_t *my, float *myo, const int lane)
+{
+    const int cbl = lane >> 2, sub = lane & 3;
+    bool valid;
+    const int cb = rowmap(cbl, valid);
+    const int chan = cb / nblk, blk = cb - chan * nblk;
+
+    float c0re, c0im, c1re, c1im;
+    float n0re = 0.0f, n0im = 0.0f, n1re = 0.0f, n1im = 0.0f;
+    if (blk == 0) {
+        c0re = st[chan].z0re; c0im = st[chan].z0im; c1re = st[chan].z1re; c1im = st[chan].z1im;
+        fe_next_z(iq, cb, nblk, n0re, n0im, n1re, n1im);
+    } else {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(iq) + (size_t)cb * kBlockSamples;
+        const uint32_t a = p[-2], b = p[-1];
+        c1re = s16_to_float((int)(short)(a & 0xFFFF)); c1im = s16_to_float((int)a >> 16);
+        c0re = s16_to_float((int)(short)(b & 0xFFFF)); c0im = s16_to_float((int)b >> 16);
+        limit(c1re, c1im);
+        limit(c0re, c0im);
+    }
+
+    // cooperative load: instruction j covers rows 8j .. 8j + 7, 8 lanes x 16 B = one 128-byte line per row
+    const int lr = lane >> 3, c8 = lane & 7;
+    auto row_ptr = [&](int j) {
+        bool v_;
+        const int row = rowmap(j * 8 + lr, v_);
+        return iq + (size_t)row * (kBlockSamples / 4) + c8;
+    };
+    const uint4 *g0 = row_ptr(0), *g1 = row_ptr(1);
+    const int l0 = lr * FL_STRIDE + c8 * 4, l1 = l0 + 8 * FL_STRIDE;
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    auto ld = [](const uint4 *p) {
+        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    constexpr int NS = DEEP ? 5 : 1;                          // stages of input in flight (chunk c + k in stage (c + k) % NS)
+    uint4 sa[NS], sb[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) { sa[k] = ld(g0 + k * (FL_CHUNK / 4)); sb[k] = ld(g1 + k * (FL_CHUNK / 4)); }
+
+    float offset = 0.0f;                                      // the row's DC sum so far, in all four lanes of the quad
+    float *dst = disc_raw + (size_t)cb * kDiscOut;
+    const bool sub0 = sub == 0;
+    float *orow = &myo[cbl * FL_STRIDE];
+
+    auto chunk_body = [&](int chunk, auto c5tag) {
+        constexpr int C5 = decltype(c5tag)::value;
+        constexpr int SG = DEEP ? C5 : 0;
+        *reinterpret_cast<uint4 *>(&my[l0]) = sa[SG];
+        *reinterpret_cast<uint4 *>(&my[l1]) = sb[SG];
+        {
+            const int nx = ((chunk + NS < FL_NCHUNK) ? chunk + NS : FL_NCHUNK - 1) * (FL_CHUNK / 4);
+            sa[SG] = ld(g0 + nx); sb[SG] = ld(g1 + nx);
+        }
+        wave_lds_sync();
+        uint32_t w[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&my[cbl * FL_STRIDE + sub * 8 + q * 4]);
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+        wave_lds_sync();                                       // every lane holds its samples: the tile is free
+        v2f z[8];
+        fe_convert<4>(&w[0], &z[0]);
+        fe_convert<4>(&w[4], &z[4]);
+        v2f p0 = {dpp_row_shr1(z[7].x), dpp_row_shr1(z[7].y)};            // sample -1 of this lane's run
+        v2f p1 = {dpp_row_shr1(z[6].x), dpp_row_shr1(z[6].y)};            // sample -2
+        if (sub0) { p0 = (v2f){c0re, c0im}; p1 = (v2f){c1re, c1im}; }
+        c0re = dpp_quad_b3(z[7].x); c0im = dpp_quad_b3(z[7].y);
+        c1re = dpp_quad_b3(z[6].x); c1im = dpp_quad_b3(z[6].y);
+        float u[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // dsp_arctan_disc2 (m17_dsp.cpp:194-222): z0 = sample e-1, z1 = sample e-2;  u = (z0.re (im - z1.im) - z0.im (re - z1.re)) / 2
+            const v2f z0 = (e >= 1) ? z[e >= 1 ? e - 1 : 0] : p0;
+            const v2f z1 = (e >= 2) ? z[e >= 2 ? e - 2 : 0] : (e == 1 ? p0 : p1);
+            const v2f d = z[e] - z1;
+            const v2f pr = d * (v2f){z0.y, z0.x};                          // (aa, bb)
+            u[e] = (pr.y - pr.x) * 0.5f;
+        }
+        // ---- strictly sequential DC sum (m17_dsp.cpp:211) through the quad
+        float T = offset;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const float left = dpp_quad_left(T);
+            T = sub0 ? offset : left;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) T = T + u[e];
+        }
+        offset = dpp_quad_b3(T);
+        // ---- count % 5 == 0 pick (m17_dsp.cpp:207-210): positions 32 C5 + 8 sub + e of the 160-sample period
+        {
+            const int m = (2 * C5 + 3 * sub) % 5;              // (first position) % 5: 32 % 5 == 2, 8 % 5 == 3
+            const int e0 = 4 - m;                              // first pick of this lane's run; the second is e0 + 5 when e0 <= 2
+            const int o0 = (C5 * 32 + 8 * sub + e0) / 5;       // its output index within the period
+            const unsigned long long k0 = __builtin_amdgcn_ballot_w64(e0 == 0), k1 = __builtin_amdgcn_ballot_w64(e0 == 1),
+                                     k2 = __builtin_amdgcn_ballot_w64(e0 == 2), k3 = __builtin_amdgcn_ballot_w64(e0 == 3);
+            float v0, v1;
+            asm("v_cndmask_b32 %0, %5, %4, %9\n\tv_cndmask_b32 %0, %0, %3, %8\n\tv_cndmask_b32 %0, %0, %2, %7\n\tv_cndmask_b32 %0, %0, %1, %6"
+                : "=&v"(v0) : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "s"(k0), "s"(k1), "s"(k2), "s"(k3));
+            asm("v_cndmask_b32 %0, %3, %2, %5\n\tv_cndmask_b32 %0, %0, %1, %4"
+                : "=&v"(v1) : "v"(u[5]), "v"(u[6]), "v"(u[7]), "s"(k0), "s"(k1));
+            orow[o0] = v0;
+            if (e0 <= 2) orow[o0 + 1] = v1;
+        }
+    };
+
+    for (int it = 0; it < FL_NCHUNK / 5; ++it) {
+        chunk_body(it * 5 + 0, std::integral_constant<int, 0>{});
+        chunk_body(it * 5 + 1, std::integral_constant<int, 1>{});
+        chunk_body(it * 5 + 2, std::integral_constant<int, 2>{});
+        chunk_body(it * 5 + 3, std::integral_constant<int, 3>{});
+        chunk_body(it * 5 + 4, std::integral_constant<int, 4>{});
+        wave_lds_sync();
+        // 32 outputs per row: the quad stores its row's 128 bytes
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(&myo[cbl * FL_STRIDE + q * 16 + sub * 4]);
+            if (valid) *reinterpret_cast<float4 *>(dst + it * 32 + q * 16 + sub * 4) = v;
+        }
+        wave_lds_sync();
+    }
+    if (sub0 && valid) {
+        offs[cb] = offset / (float)kBlockSamples;
+        if (update_state && blk == 0) {
+            st[chan].z0re = n0re; st[chan].z0im = n0im; st[chan].z1re = n1re; st[chan].z1im = n1im;
+        }
+    }
+}
+// the stand-alone launch of that tile: sixteen consecutive rows per wave (option fe_impl 4)
+__global__ __launch_bounds__(64, 6)
+void k_frontend_l(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
+                  float *__restrict__ disc_raw, float *__restrict__ offs,
+                  int nblk, int total, int update_state)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[16 * FL_STRIDE];
+    __shared__ __attribute__((aligned(16))) float otile[16 * FL_STRIDE];
+    const int cb0 = (int)blockIdx.x * 16;
+    if (cb0 >= total) return;
+    frontend_lite_tile(iq, st, disc_raw, offs, nblk, update_state,
+                       [&](int i, bool &valid) { valid = cb0 + i < total; return valid ? cb0 + i : total - 1; }, tile, otile, lane_id());
+}
+
 __global__ __launch_bounds__(64 * FQ_WAVES, 4)
 void k_frontend_d(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
                   float *__restrict__ disc_raw, float *__restrict__ offs,

@@ -239,7 +239,21 @@ __device__ __forceinline__ int hunt_pass(int pos, int n, int gl, Ld ld, SyncResu
     const unsigned sgn = sync_sign_mask(gl);
     while (cm) {
         const int l = (int)__builtin_ctzll(cm);
-        const SyncResult r = sync_check_lanes8(ld(pos + l - 7 + (gl & 7)), sgn);
+        const float vs = ld(pos + l - 7 + (gl & 7));
+        // A window that passed the sign filter is accepted only with (max - min) / max < 0.3 over its magnitudes
+        // (find_variance, m17_rx_frame.cpp:22-43,92-103).  min < 0.69 max puts that quotient above 0.3099 whatever the
+        // rounding of its two operations: such a window is rejected here for a dozen instructions instead of the check's
+        // sixty-odd (template sums, argmax, votes, the exact quotient) -- in noise that is nearly every window that got this
+        // far (round 5: item 5 of the round-4 review).  No NaN and no zero reaches this point (the sign filter).
+        {
+            const float a = __builtin_fabsf(vs);
+            float mx = a, mn = a;
+            mx = __builtin_fmaxf(mx, dpp_own_f<0xB1>(mx)); mn = __builtin_fminf(mn, dpp_own_f<0xB1>(mn));      // lane ^ 1
+            mx = __builtin_fmaxf(mx, dpp_own_f<0x4E>(mx)); mn = __builtin_fminf(mn, dpp_own_f<0x4E>(mn));      // lane ^ 2
+            mx = __builtin_fmaxf(mx, dpp_own_f<0x141>(mx)); mn = __builtin_fminf(mn, dpp_own_f<0x141>(mn));    // row_half_mirror
+            if (unif(mn) < 0.69f * unif(mx)) { cm &= cm - 1ull; continue; }
+        }
+        const SyncResult r = sync_check_lanes8(vs, sgn);
         if (sync_accept(r, false)) { out = r; return l; }
         cm &= cm - 1ull;
     }

@@ -57,8 +57,21 @@ static_assert(sizeof(WvChan) == 4096, "WvChan layout");
     [acc] "=&v"(acc), [p] "=&v"(P), [q] "=&v"(Q), [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3),        \
     [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6), [x7] "=&v"(x7), [x8] "=&v"(x8), [x9] "=&v"(x9), [x10] "=&v"(x10),   \
     [x11] "=&v"(x11), [x12] "=&v"(x12), [x13] "=&v"(x13), [x14] "=&v"(x14), [x15] "=&v"(x15)
+#define M17_TAP_CLOBBERS_H "s36","s37","s38","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s50", \
+    "s51","s52","s53","s54","s55","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67"
+#define M17_FIR_OPERANDS_H                                                                                               \
+    [acc] "=&v"(acc), [p] "=&v"(P), [q] "=&v"(Q), [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3),        \
+    [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6), [x7] "=&v"(x7)
+// HALF: the window through eight registers, read twice (m17_fir_sgpr.inc, *_H): 16 VGPRs less per lane, one more wait on LDS per round
+template <int HALF = 0>
 __device__ __forceinline__ v2f fir_window_s(const float *row, unsigned lds_pair, bool odd)
 {
+    if (HALF) {
+        v2f acc, P, Q, x0, x1, x2, x3, x4, x5, x6, x7;
+        if (!odd) asm volatile(M17_FIR_SGPR_EVEN_H : M17_FIR_OPERANDS_H : [a] "v"(lds_pair), [row] "s"(row) : "memory", M17_TAP_CLOBBERS_H);
+        else      asm volatile(M17_FIR_SGPR_ODD_H : M17_FIR_OPERANDS_H : [a] "v"(lds_pair), [row] "s"(row) : "memory", M17_TAP_CLOBBERS_H);
+        return acc;
+    }
     v2f acc, P, Q, x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
     if (!odd) asm volatile(M17_FIR_SGPR_EVEN : M17_FIR_OPERANDS : [a] "v"(lds_pair), [row] "s"(row) : "memory", M17_TAP_CLOBBERS);
     else      asm volatile(M17_FIR_SGPR_ODD : M17_FIR_OPERANDS : [a] "v"(lds_pair), [row] "s"(row) : "memory", M17_TAP_CLOBBERS);
@@ -130,6 +143,7 @@ struct WvCtl {
 // m17_rx_sync_samples (m17_rx_sync.cpp:77-99) over ONE block of 384 inputs: x[i .. i+30] is the delay line at input i,
 // xb the LDS byte address of x[0] (8-byte aligned; up to 124 floats behind x[413] are read and never used), hb that of
 // the channel's symbol ring.  Rounds of 64 instants; symbols go into the ring from t.hp on.  Returns the symbol count.
+template <int HALF = 0>
 __device__ __forceinline__ int wv_timing_block(WvCtl &t, const unsigned xb, const unsigned hb, const int gl, const int lockv, unsigned *wst)
 {
     constexpr int LPC = 64;
@@ -160,7 +174,7 @@ __device__ __forceinline__ int wv_timing_block(WvCtl &t, const unsigned xb, cons
         // Lane g takes the instant at input p + 2g.  Near the end of the block the upper lanes run past it: their
         // windows read what follows the block in the channel's LDS, and nothing of theirs is used -- no vote (okm),
         // no symbol (naccept <= nv), no carried value.
-        const v2f a = fir_window_s(&c_tab.tap_pairs[t.index][0], ((unsigned)gl << 3) + (xb + ((unsigned)(p & ~1) << 2)), (p & 1) != 0);
+        const v2f a = fir_window_s<HALF>(&c_tab.tap_pairs[t.index][0], ((unsigned)gl << 3) + (xb + ((unsigned)(p & ~1) << 2)), (p & 1) != 0);
         WSTAMP(1);
         const float s = a.x, d = a.y;
         const int rem = kDiscOut - p;                     // >= 1
@@ -323,6 +337,7 @@ __device__ __forceinline__ void wv_store_state(const WvCtl &t, ChanState &cs, in
 
 // the whole call of ONE channel by the calling wave; `my` = the channel's 4 KB of LDS (4 KB-aligned), wave = the wave's
 // index in its workgroup (instrumented build only)
+template <int HALF = 0>
 __device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc, const float *__restrict__ offs,
                        ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
                        m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
@@ -380,7 +395,7 @@ __device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc
     for (int b = b0; b < bend; ++b) {
         WSTAMP(5);
         // m17_rx_lock(): the framer's state after the previous block
-        const int n = wv_timing_block(t, xb, hb, gl, (ext_lock >= 0) ? ext_lock : t.flock, wst);
+        const int n = wv_timing_block<HALF>(t, xb, hb, gl, (ext_lock >= 0) ? ext_lock : t.flock, wst);
         wave_fence();
         // next block's input: requested here, behind the filter rounds (whose 40-odd window registers leave no room
         // for six more), and moved into x[] at the end of the block, behind the framer
@@ -434,9 +449,12 @@ __device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc
 #endif
 }
 
-// (six waves per SIMD: a seventh -- 72 VGPRs, amdgpu_waves_per_eu(7, 7), 16 B of scratch -- changes nothing, 0.294-0.303 against
-//  0.302 ms on one box, round 4; eight with 14 VGPRs in scratch are slower, round 3)
-__global__ __launch_bounds__(64 * WV_WAVES, 6)
+// Two builds of the kernel.  <0, 6>: the filter of a round as one statement with the branch's 62 tap registers and 16 window
+// registers: 106 SGPRs, which admit six waves per SIMD (a seventh changes nothing, eight with registers in scratch are
+// slower: rounds 3 and 4).  <1, 8> (round 5): taps and window through half the registers, twice per round
+// (fir_window_s<1>): 78 SGPRs and 61 VGPRs, EIGHT waves per SIMD -- 8,192 wave slots, two even generations of 16,384 channels.
+template <int HALF, int OCC>
+__global__ __launch_bounds__(64 * WV_WAVES, OCC)
 void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
                        const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
                        ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
@@ -446,8 +464,8 @@ void k_sync_frame_wave(const float *__restrict__ disc,     // [C][nblk][384]
 {
     __shared__ __attribute__((aligned(4096))) WvChan chs[WV_WAVES];
     const int wave = uni((int)(threadIdx.x >> 6));
-    sync_wave_channel(disc, offs, st, C, nblk, mode, ext_lock, recs, rec_cap, counts, syms, nsyms, fsym, b0, bcount,
-                      (int)blockIdx.x * WV_WAVES + wave, chs[wave], wave);
+    sync_wave_channel<HALF>(disc, offs, st, C, nblk, mode, ext_lock, recs, rec_cap, counts, syms, nsyms, fsym, b0, bcount,
+                            (int)blockIdx.x * WV_WAVES + wave, chs[wave], wave);
 }
 
 #ifdef M17_STAMPS

@@ -56,6 +56,7 @@ struct m17gpu_ctx {
     int sync_impl = 0;                       // 0 | 6 = timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond (default);
                                              // 7 = wave per channel at every size
     int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
+    int rc_slots = 0;                        // EXPERIMENT: compact row region of k_rx_chan6 (0 = the channel's own rows)
     int32_t *d_flags = nullptr;              // [n_flags] verdict words of m17gpu_shard_gather_packed
     int n_flags = 0;
     int fir_impl = 0;                        // 0 | 1 = front end + timing kernel (default); 2 = the fused FIR-stage kernel (m17_fused.hip:
@@ -177,7 +178,10 @@ int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc,
     // measured on MI355X (scripts/exp_scale.py): the 4-lane kernel wins at 51,200 .. 196,608 channel-blocks,
     // so it is the default at every size; fe_impl 1 keeps the one-lane kernel selectable
     const bool quad = ctx->fe_impl != 1;
-    if (ctx->fe_impl == 3)
+    if (ctx->fe_impl == 4)
+        hipLaunchKernelGGL(k_frontend_l, dim3(cdiv(total, 16)), dim3(64), 0, st,
+                           reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state);
+    else if (ctx->fe_impl == 3)
         hipLaunchKernelGGL(k_frontend_d, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state);
     else if (quad)
@@ -212,10 +216,12 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
         hipLaunchKernelGGL(k_sync_frame_duo, dim3(cdiv(cn, 4)), dim3(512), 0, st,
                            disc, offs, state, cn, nblk, mode, recs, recs ? rec_cap : 0,
                            counts, syms, nsyms, fsym, b0, bcount);
-    else
-        hipLaunchKernelGGL(k_sync_frame_wave, dim3(cdiv(cn, WV_WAVES)), dim3(64 * WV_WAVES), 0, st,
+    else {
+        auto kern = ctx->sync_impl == 8 ? k_sync_frame_wave<1, 8> : ctx->sync_impl == 9 ? k_sync_frame_wave<1, 6> : k_sync_frame_wave<0, 6>;
+        hipLaunchKernelGGL(kern, dim3(cdiv(cn, WV_WAVES)), dim3(64 * WV_WAVES), 0, st,
                            disc, offs, state, cn, nblk, mode, ext_lock, recs, recs ? rec_cap : 0,
                            counts, syms, nsyms, fsym, b0, bcount);
+    }
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -226,12 +232,13 @@ bool use_fused(const m17gpu_ctx *ctx) { return !ctx->afc && (ctx->fir_impl >= 2)
 int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
                  int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st)
 {
-    if (ctx->fir_impl == 4)
-        hipLaunchKernelGGL(k_rx_chan<1>, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
+    if (ctx->fir_impl == 4) {
+        // the same built for six waves per SIMD (k_rx_chan6)
+        hipLaunchKernelGGL((k_rx_chan6<1, 6, false>), dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->C, nblk, mode,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
-                           d_syms, d_nsyms, ctx->d_fsym);
-    else if (ctx->fir_impl == 3)
+                           d_syms, d_nsyms, ctx->d_fsym, ctx->rc_slots);
+    } else if (ctx->fir_impl == 3)
         // wave per channel, sixteen of its own blocks per front-end tile, rows handed over through the workspace (k_rx_chan)
         hipLaunchKernelGGL(k_rx_chan<0>, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->C, nblk, mode,
@@ -438,6 +445,18 @@ int m17gpu_debug_pc_mock(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *
     return M17GPU_OK;
 }
 
+int m17gpu_debug_ptrs(m17gpu_ctx *ctx, unsigned long long *out /* [6] */)
+{
+    out[0] = (unsigned long long)ctx->d_state; out[1] = (unsigned long long)ctx->d_disc; out[2] = (unsigned long long)ctx->d_offs;
+    out[3] = (unsigned long long)ctx->d_fsym; out[4] = (unsigned long long)ctx->d_counts; out[5] = (unsigned long long)ctx->d_work;
+    return 0;
+}
+int m17gpu_debug_rc_stamps(unsigned long long *out /* [16384][4] */)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rc_stamps), sizeof(unsigned long long) * 16384 * 4));
+    return 0;
+}
 int m17gpu_debug_stamps(unsigned long long *out)
 {
     HIPCHK(hipDeviceSynchronize());
@@ -506,10 +525,13 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
     auto bad = [&]() { return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: value out of range for ") + name); };
-    if (!std::strcmp(name, "sync_impl")) { if (value != 0 && value != 6 && value != 7) return bad(); ctx->sync_impl = value; }
-    else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 3) return bad(); ctx->fe_impl = value; }
+    if (!std::strcmp(name, "sync_impl")) { if (value != 0 && (value < 6 || value > 9)) return bad(); ctx->sync_impl = value; }
+    else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 4) return bad(); ctx->fe_impl = value; }
     else if (!std::strcmp(name, "fir_impl")) { if (value < 0 || value > 4) return bad(); ctx->fir_impl = value; }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
+#ifdef M17_STAMPS
+    else if (!std::strcmp(name, "rc_slots")) { ctx->rc_slots = value; }      // instrumented build only: rows may collide, WRONG results
+#endif
 #ifdef M17_STAMPS
     else if (!std::strcmp(name, "fe_debug")) { ctx->fe_debug = value; }      // instrumented build only: WRONG results
 #endif
