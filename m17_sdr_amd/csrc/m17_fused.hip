@@ -278,7 +278,6 @@ __device__ __forceinline__ int rc_lane()
 #ifdef M17_STAMPS
 __device__ unsigned long long g_rc_stamps[16384][4];          // per channel: ticks in front-end tiles, in timing phases, realtime in / out
 #endif
-template <int HALF>
 __global__ __launch_bounds__(64 * RC_WAVES, 4)
 void k_rx_chan(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float *__restrict__ disc, float *__restrict__ offs,
                int C, int nblk, int mode, m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
@@ -306,8 +305,8 @@ void k_rx_chan(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float *
 #ifdef M17_STAMPS
         { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fe += now - t_last; t_last = now; }
 #endif
-        sync_wave_channel<HALF>(disc, offs, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, min(16, nblk - b0),
-                                chan, wc, wave, rc_lane());
+        sync_wave_channel<0>(disc, offs, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, min(16, nblk - b0),
+                             chan, wc, wave, rc_lane());
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // channel state out before the next group reads it
         wave_lds_sync();
 #ifdef M17_STAMPS
@@ -328,11 +327,10 @@ void k_rx_chan(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float *
 // profiles/r03_issue_rates_gfx950.txt), so what a SIMD gets done grows with the waves it holds: 4 -> 6 waves is +15..20 %.
 constexpr int RC6_LDS = 6144;                  // per wave: the two 2,304-byte tiles / the timing loop's WvChan (4 KB); a multiple of 2 KB (ring alignment)
 static_assert(RC6_LDS >= 2 * FL_TILE_BYTES && RC6_LDS >= (int)sizeof(WvChan) && RC6_LDS % 2048 == 0, "k_rx_chan6 LDS layout");
-template <int HALF, int OCC, bool DEEP>
-__global__ __launch_bounds__(64 * RC_WAVES, OCC)
+__global__ __launch_bounds__(64 * RC_WAVES, 6)
 void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float *__restrict__ disc, float *__restrict__ offs,
                 int C, int nblk, int mode, m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
-                float *__restrict__ syms, int32_t *__restrict__ nsyms, float *__restrict__ fsym, int nslots)
+                float *__restrict__ syms, int32_t *__restrict__ nsyms, float *__restrict__ fsym)
 {
     __shared__ __attribute__((aligned(4096))) unsigned char lds[RC_WAVES][RC6_LDS];
     const int wave = uni((int)(threadIdx.x >> 6));
@@ -348,23 +346,16 @@ void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float 
 #endif
     for (int b0 = 0; b0 < nblk; b0 += 16) {
         const int bc = min(16, nblk - b0);
-        // where the group's sixteen rows travel: the channel's own rows of the workspace, or (EXPERIMENT, nslots > 0) a
-        // compact region of nslots x 16 rows that stays in the cache levels -- row r of the group at slot * 16 + r
-        float *dw = disc, *ow = offs;
-        if (nslots > 0) {
-            const int slot = chan % nslots;
-            dw = disc + ((size_t)slot * 16 - (size_t)(row0 + b0)) * kDiscOut;
-            ow = offs + ((size_t)slot * 16 - (size_t)(row0 + b0));
-        }
+        float *const dw = disc, *const ow = offs;
         // rows b0 .. b0 + 15 of this channel (rows past its last block are computed on its last row and never stored)
-        frontend_lite_tile<DEEP>(iq, st, dw, ow, nblk, 1,
+        frontend_lite_tile(iq, st, dw, ow, nblk, 1,
                                  [&](int i, bool &valid) { valid = i < bc; return row0 + b0 + (valid ? i : bc - 1); }, tile, otile, rc_lane());
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the rows are in memory before this wave reads them back
         wave_lds_sync();
 #ifdef M17_STAMPS
         { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fe += now - t_last; t_last = now; }
 #endif
-        sync_wave_channel<HALF>(dw, ow, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, bc,
+        sync_wave_channel<1>(dw, ow, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, bc,
                                 chan, wc, wave, rc_lane());
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // channel state out before the next group reads it
         wave_lds_sync();

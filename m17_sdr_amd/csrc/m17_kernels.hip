@@ -725,9 +725,8 @@ __device__ __forceinline__ void frontend_g_tile(const uint4 *__restrict__ iq, Ch
 // ---------------------------------------------------------------------------
 constexpr int FL_CHUNK = 32, FL_STRIDE = 36, FL_NCHUNK = kBlockSamples / FL_CHUNK;    // 60 chunks per block
 constexpr int FL_TILE_BYTES = 16 * FL_STRIDE * 4;                                      // 2,304 B each, raw and output
-// DEEP: five chunks (10 KB per wave) of input in flight instead of one -- a wave that shares its SIMD with waves in the
-// timing phase is one of few that stream, and with one chunk in flight each they do not cover the memory latency
-template <bool DEEP = false, class RowMap>
+// (five chunks of input in flight per wave instead of one -- 40 more VGPRs -- changed nothing: profiles/r05_rx_chan_variants.txt)
+template <class RowMap>
 __device__ __forceinline__ void frontend_lite_tile(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
                                                    float *__restrict__ disc_raw, float *__restrict__ offs,
                                                    int nblk, int update_state, RowMap rowmap, uint32_t *my, float *myo, const int lane)
@@ -765,10 +764,7 @@ __device__ __forceinline__ void frontend_lite_tile(const uint4 *__restrict__ iq,
         const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
         return make_uint4(v.x, v.y, v.z, v.w);
     };
-    constexpr int NS = DEEP ? 5 : 1;                          // stages of input in flight (chunk c + k in stage (c + k) % NS)
-    uint4 sa[NS], sb[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) { sa[k] = ld(g0 + k * (FL_CHUNK / 4)); sb[k] = ld(g1 + k * (FL_CHUNK / 4)); }
+    uint4 s0 = ld(g0), s1 = ld(g1);
 
     float offset = 0.0f;                                      // the row's DC sum so far, in all four lanes of the quad
     float *dst = disc_raw + (size_t)cb * kDiscOut;
@@ -777,12 +773,11 @@ __device__ __forceinline__ void frontend_lite_tile(const uint4 *__restrict__ iq,
 
     auto chunk_body = [&](int chunk, auto c5tag) {
         constexpr int C5 = decltype(c5tag)::value;
-        constexpr int SG = DEEP ? C5 : 0;
-        *reinterpret_cast<uint4 *>(&my[l0]) = sa[SG];
-        *reinterpret_cast<uint4 *>(&my[l1]) = sb[SG];
+        *reinterpret_cast<uint4 *>(&my[l0]) = s0;
+        *reinterpret_cast<uint4 *>(&my[l1]) = s1;
         {
-            const int nx = ((chunk + NS < FL_NCHUNK) ? chunk + NS : FL_NCHUNK - 1) * (FL_CHUNK / 4);
-            sa[SG] = ld(g0 + nx); sb[SG] = ld(g1 + nx);
+            const int nx = ((chunk + 1 < FL_NCHUNK) ? chunk + 1 : chunk) * (FL_CHUNK / 4);
+            s0 = ld(g0 + nx); s1 = ld(g1 + nx);
         }
         wave_lds_sync();
         uint32_t w[8];

@@ -56,7 +56,6 @@ struct m17gpu_ctx {
     int sync_impl = 0;                       // 0 | 6 = timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond (default);
                                              // 7 = wave per channel at every size
     int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
-    int rc_slots = 0;                        // EXPERIMENT: compact row region of k_rx_chan6 (0 = the channel's own rows)
     int32_t *d_flags = nullptr;              // [n_flags] verdict words of m17gpu_shard_gather_packed
     int n_flags = 0;
     int fir_impl = 0;                        // 0 | 1 = front end + timing kernel (default); 2 = the fused FIR-stage kernel (m17_fused.hip:
@@ -217,7 +216,9 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
                            disc, offs, state, cn, nblk, mode, recs, recs ? rec_cap : 0,
                            counts, syms, nsyms, fsym, b0, bcount);
     else {
-        auto kern = ctx->sync_impl == 8 ? k_sync_frame_wave<1, 8> : ctx->sync_impl == 9 ? k_sync_frame_wave<1, 6> : k_sync_frame_wave<0, 6>;
+        // default (0 / 6 beyond 1,024 channels, and 8): taps and window through half the registers, eight waves per SIMD;
+        // 7 = round 3's form (all 62 tap registers, six waves per SIMD), 9 = the half-register form at six waves per SIMD
+        auto kern = ctx->sync_impl == 7 ? k_sync_frame_wave<0, 6> : ctx->sync_impl == 9 ? k_sync_frame_wave<1, 6> : k_sync_frame_wave<1, 8>;
         hipLaunchKernelGGL(kern, dim3(cdiv(cn, WV_WAVES)), dim3(64 * WV_WAVES), 0, st,
                            disc, offs, state, cn, nblk, mode, ext_lock, recs, recs ? rec_cap : 0,
                            counts, syms, nsyms, fsym, b0, bcount);
@@ -228,19 +229,29 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
 
 // The FIR stage as ONE kernel (m17_fused.hip): front end, timing loop and framer of a channel in one wave, the
 // discriminator samples never leaving the CU.  Not the default: DESIGN.md section 6 (round 4) has the measurements.
-bool use_fused(const m17gpu_ctx *ctx) { return !ctx->afc && (ctx->fir_impl >= 2); }
+// Which FIR stage runs.  fir_impl 0 (default): the wave-per-channel kernel k_rx_chan6 where it wins -- calls of whole
+// sixteen-block groups (its front-end tiles are sixteen of a channel's own blocks) on batches that give the chip at least
+// two waves per slot (measured at 16,384 channels: -8 % on the full chain at 16 blocks per call, +8 % at 12; nothing
+// at 4,096) -- and front end + timing kernel otherwise.
+int fir_choice(const m17gpu_ctx *ctx, int nblk)
+{
+    if (ctx->afc) return 1;
+    if (ctx->fir_impl != 0) return ctx->fir_impl;
+    return (nblk % 16 == 0 && ctx->C >= 8192) ? 4 : 1;
+}
 int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
                  int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st)
 {
-    if (ctx->fir_impl == 4) {
+    const int fir = fir_choice(ctx, nblk);
+    if (fir == 4) {
         // the same built for six waves per SIMD (k_rx_chan6)
-        hipLaunchKernelGGL((k_rx_chan6<1, 6, false>), dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
+        hipLaunchKernelGGL(k_rx_chan6, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->C, nblk, mode,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
-                           d_syms, d_nsyms, ctx->d_fsym, ctx->rc_slots);
-    } else if (ctx->fir_impl == 3)
+                           d_syms, d_nsyms, ctx->d_fsym);
+    } else if (fir == 3)
         // wave per channel, sixteen of its own blocks per front-end tile, rows handed over through the workspace (k_rx_chan)
-        hipLaunchKernelGGL(k_rx_chan<0>, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
+        hipLaunchKernelGGL(k_rx_chan, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->C, nblk, mode,
                            reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
                            d_syms, d_nsyms, ctx->d_fsym);
@@ -409,7 +420,7 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
             }
             MARK(1);
             MARK(2);
-        } else if (use_fused(ctx)) {
+        } else if (fir_choice(ctx, nblk) >= 2) {
             MARK(1);                             // no separate front end: stage 0 reads as zero, stage 1 is the fused kernel
             if ((rc = launch_fused(ctx, d_iq, nblk, mode, d_recs, rec_cap, d_counts, d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
             MARK(2);
@@ -503,8 +514,8 @@ int m17gpu_selftest(m17gpu_ctx *ctx, unsigned *h_bad)
     if (!ctx || !h_bad) return fail(M17GPU_ERR_ARG, "m17gpu_selftest: bad argument");
     ON_CTX_DEVICE(ctx);
     unsigned *d_bad = nullptr;
-    HIPCHK(hipMalloc(&d_bad, 4 * sizeof(unsigned)));
-    HIPCHK(hipMemset(d_bad, 0, 4 * sizeof(unsigned)));
+    HIPCHK(hipMalloc(&d_bad, 8 * sizeof(unsigned)));
+    HIPCHK(hipMemset(d_bad, 0, 8 * sizeof(unsigned)));
     hipLaunchKernelGGL(k_selftest_scale, dim3(256), dim3(256), 0, nullptr, d_bad + 0);
     // a = re^2 + im^2 lies in [9e-10, 2]; sweep every float in [2^-32, 8)
     hipLaunchKernelGGL(k_selftest_sqrt, dim3(4096), dim3(256), 0, nullptr, 0x2F800000u, 0x41000000u, d_bad + 1);
@@ -514,6 +525,7 @@ int m17gpu_selftest(m17gpu_ctx *ctx, unsigned *h_bad)
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(h_bad, d_bad, 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
+
     (void)hipFree(d_bad);
     return M17GPU_OK;
 }
@@ -529,9 +541,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 4) return bad(); ctx->fe_impl = value; }
     else if (!std::strcmp(name, "fir_impl")) { if (value < 0 || value > 4) return bad(); ctx->fir_impl = value; }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
-#ifdef M17_STAMPS
-    else if (!std::strcmp(name, "rc_slots")) { ctx->rc_slots = value; }      // instrumented build only: rows may collide, WRONG results
-#endif
+
 #ifdef M17_STAMPS
     else if (!std::strcmp(name, "fe_debug")) { ctx->fe_debug = value; }      // instrumented build only: WRONG results
 #endif

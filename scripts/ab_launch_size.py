@@ -11,7 +11,8 @@ BYTES = 8448 if mode == 0 else 7744
 for nblk in sizes:
     T = max(4, min(12, 288 // nblk))
     gen = m.Receiver(C, nblk)
-    big = gen.gen_batch(nblk * T, n_stream_frames=40)["iq"]
+    eb = float(os.environ.get("M17_EBN0", "200"))
+    big = gen.gen_batch(nblk * T, n_stream_frames=40, ebn0_db=eb, noise_cutoff_hz=6250.0 if eb < 100 else 0.0)["iq"]
     slabs = torch.empty((T, C, nblk, 1920, 2), dtype=torch.int16, device=big.device)
     slabs.copy_(big.view(C, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4))
     del big
