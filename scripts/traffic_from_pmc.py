@@ -15,9 +15,10 @@ def pm(path):
 res = {"_comment": ("HBM-side bytes per m17gpu_rx_blocks launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                     "scripts/collect_profiles.sh), KB x 1024, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide "
                     "coalesced reads); raw counters: profiles/%s_pmc_*.txt; built by scripts/traffic_from_pmc.py. Includes the streams "
-                    "one kernel writes for the next to read (discriminator stream 1.5 KB per channel-block; frame slots 1.6 KB per "
-                    "stream frame in the full chain).") % tag, "_profile_prefix": tag, "_per_kernel_MB": {}}
-for wl, key in (("full", "full:16384x12"), ("frontend", "frontend:1024x50"), ("frontend_16384x12", "frontend:16384x12"), ("full_noisy", "full-noisy:16384x12")):
+                    "one kernel writes for the next to read, or a wave for itself (discriminator rows 1.5 KB per channel-block; frame slots "
+                    "1.6 KB per stream frame in the full chain).") % tag, "_profile_prefix": tag, "_per_kernel_MB": {}}
+for wl, key in (("full", "full:16384x16"), ("full_12", "full:16384x12"), ("frontend", "frontend:1024x50"), ("frontend_16384x16", "frontend:16384x16"),
+                ("frontend_16384x12", "frontend:16384x12"), ("frontend_16384x48", "frontend:16384x48"), ("full_noisy", "full-noisy:16384x16")):
     if not os.path.exists(os.path.join(src, f"pmc_FETCH_SIZE_{wl}.txt")):
         continue
     f = pm(os.path.join(src, f"pmc_FETCH_SIZE_{wl}.txt")); w = pm(os.path.join(src, f"pmc_WRITE_SIZE_{wl}.txt"))

@@ -299,3 +299,4 @@ def test_traffic_json_comes_from_the_newest_profile_set():
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             assert os.path.exists(os.path.join(ROOT, "profiles", f"{prefixes[-1]}_pmc_{c}_{wl}.txt"))
     assert tj["full:16384x12"] > 196608 * 7744 and tj["frontend:1024x50"] > 51200 * 8448
+    assert tj["full:16384x16"] > 262144 * 7744 and tj["frontend:16384x16"] > 262144 * 8448     # the bench's default step since round 5
