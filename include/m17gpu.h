@@ -142,14 +142,22 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  * Every accepted value selects a kernel held to bit-exact parity; anything else returns
  * M17GPU_ERR_ARG:
  *   "sync_impl"          0 | 6 = by size (default): timing wave + framer wave per channel, decoupled by one
- *                            block, up to 1,024 channels; one wave per channel with scalar control and
- *                            the filter taps in SGPRs beyond; 7 = that kernel at every size
+ *                            block, up to 1,024 channels; beyond, one wave per channel with scalar control and the
+ *                            filter taps in SGPRs, taps and window through half the registers at eight waves per
+ *                            SIMD; 8 = that kernel at every size, 9 = the same at six waves per SIMD, 7 = round 3's
+ *                            form of it (all 62 tap registers at once, six waves per SIMD)
  *   "fe_impl"            0 = by size (default), 1 = lane per channel-block, 2 = four lanes per
- *                            channel-block, 3 = four lanes with the DC chain and the /5 pick in registers
- *   "fir_impl"           0 | 1 = front end and timing / framer as two kernels (default); 2 = the whole FIR stage
- *                            of a channel in one wave (k_rx_fused: no discriminator stream in HBM; measured slower,
- *                            DESIGN.md section 6); 3 = a wave per channel that runs the front end over sixteen of its
- *                            own blocks at a time and the timing loop / framer behind it (k_rx_chan)
+ *                            channel-block, 3 = four lanes with the DC chain and the /5 pick in registers,
+ *                            4 = the same on 32-sample chunks (76 VGPRs, 4.6 KB of LDS: the tile of k_rx_chan6)
+ *   "fir_impl"           0 = by call (default): 4 for calls of whole sixteen-block groups on >= 8,192 channels,
+ *                            else 1; 1 = front end and timing / framer as two kernels; 2 = the whole FIR stage of a
+ *                            channel in one wave, four blocks at a time through LDS (k_rx_fused: no discriminator rows
+ *                            in HBM; measured slower); 3 = a wave per channel that runs the front
+ *                            end over sixteen of its own blocks at a time and the timing loop / framer behind it, the
+ *                            rows through the workspace (k_rx_chan); 4 = that built for six waves per SIMD (k_rx_chan6)
+ *   "slot_impl"          how the framer hands a stream frame to the decoder: 1 = its 192 symbols (768 B; the decoder stages
+ *                            them in LDS), 2 = regrouped into the order the decoder reads (1,600 B), 0 = by path (default):
+ *                            1 behind the wave-per-channel FIR stage, 2 behind front end + timing kernel
  * and one functional switch:
  *   "afc"                0 (default, as the reference ships: radio.cpp:8) | 1 = radio_set_afc_on(): the
  *                            NCO mixer of m17_dsp.cpp:390-408,468 with the loop of radio.cpp:196-208 per channel.

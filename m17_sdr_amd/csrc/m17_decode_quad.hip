@@ -35,16 +35,18 @@ constexpr int DQ_DECW_STREAM = 19;             // ceil(148 / 8): stream frames
 // Per-frame LDS.  The record payload bytes are assembled after the forward pass, in the ring's place.
 // DECW = 31: 624 B = 4 x 39 dwords, DECW = 19: 432 B = 4 x 27 dwords -- either way the 16 frames of a wave
 // start 4 banks apart modulo 64, so the same field of all frames tiles the banks.
-template <int DECW>
+template <int DECW, int NSYM = 0>
 struct alignas(16) QuadFrameT {
     uint32_t dec[DECW][4];                     // decision nibbles: byte [t/2][quad lane], two steps per byte
     union {
         float   ring[DQ_RING];                 // soft bits of the current chunk, (m1, m2) pairs
         uint8_t bytes[32];                     // record payload
     };
+    float sym[NSYM ? NSYM : 4];                // NSYM = 192 (slot_impl 1): the frame's symbols, staged here from a plain 768-byte slot
     static constexpr int kDecw = DECW;
+    static constexpr int kNsym = NSYM;
 };
-static_assert(sizeof(QuadFrameT<DQ_DECW>) == 16 * DQ_DECW + 8 * DQ_CHUNK && sizeof(QuadFrameT<DQ_DECW_STREAM>) == 16 * DQ_DECW_STREAM + 8 * DQ_CHUNK, "QuadFrame layout");
+static_assert(sizeof(QuadFrameT<DQ_DECW>) == 16 * DQ_DECW + 8 * DQ_CHUNK + 16 && sizeof(QuadFrameT<DQ_DECW_STREAM>) == 16 * DQ_DECW_STREAM + 8 * DQ_CHUNK + 16, "QuadFrame layout");
 
 template <int CTRL> __device__ __forceinline__ float dppf(float v)
 {
@@ -141,8 +143,8 @@ void k_worklist(const m17gpu_rec_dev *__restrict__ recs, int rec_cap, const int3
 // frame needs first -- the 8 sync symbols, the LICH symbols, the first chunk -- is requested in one go at the top, and
 // the two dependent Golay table reads ride under the forward pass, so a frame pays one memory round trip, not five.
 // Fences inside are wave-local LDS fences: a workgroup-scope fence would also drain the loads in flight.
-template <int DECW, int TYPE_CT>
-__device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW> &F, const float *__restrict__ gs, const uint32_t *gt,
+template <int DECW, int TYPE_CT, int NSYM = 0>
+__device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW, NSYM> &F, const float *__restrict__ gs_in, const uint32_t *gt,
                                                  const DqLich *lich, int type_rt, int j, bool writeback, uint32_t r0_keep,
                                                  m17gpu_rec_dev *rec, const v2f (&C1)[2], const v2f (&C2)[2],
                                                  const uint16_t *genc, const uint16_t *gerr,
@@ -157,7 +159,20 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW> &F, const floa
     // m17_dev.h kSlotFloats): lane j makes ring[16j .. 16j+15] from 64 contiguous bytes of the slot.
     // (the table entry is read again at commit time: holding 16 of them across the butterflies costs registers the
     //  16-waves-per-CU budget of 128 does not have)
-    constexpr bool REGROUPED = (TYPE_CT == 2);
+    constexpr bool REGROUPED = (TYPE_CT == 2) && NSYM == 0;
+    // slot_impl 1 (round 5, NSYM == 192): the slot holds the frame's 192 symbols as the framer has them (768 B instead of the
+    // regrouped 1,600); the quad copies them into LDS in one contiguous read and every gather below goes there
+    const float *gs = gs_in;
+    if constexpr (NSYM != 0) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(gs_in) + (NSYM / 16) * j;
+        float4 t[NSYM / 16];
+#pragma unroll
+        for (int r = 0; r < NSYM / 16; ++r) t[r] = g4[r];
+#pragma unroll
+        for (int r = 0; r < NSYM / 16; ++r) reinterpret_cast<float4 *>(F.sym)[(NSYM / 16) * j + r] = t[r];
+        wave_fence();
+        gs = F.sym;
+    }
     float raw[2 * DQ_CHUNK / 4];
     float ncor;
     auto fetch_chunk = [&](int c0) {
@@ -340,9 +355,9 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW> &F, const floa
 // Workgroup-shared storage of the decoder for WAVES waves, each on its own 16 frames.
 // ONLY == 2: stream frames only: per-frame LDS sized for 148 trellis steps, one shared table row.
 // ONLY == 0: any frame type, a table row per wave.
-template <int ONLY, int WAVES>
+template <int ONLY, int WAVES, int NSYM = 0>
 struct alignas(16) DqShared {
-    QuadFrameT<(ONLY == 2) ? DQ_DECW_STREAM : DQ_DECW> fr[WAVES][DQ_FRAMES];   // 6.75 KB (stream) / 9.75 KB per wave
+    QuadFrameT<(ONLY == 2) ? DQ_DECW_STREAM : DQ_DECW, NSYM> fr[WAVES][DQ_FRAMES];   // 7 KB (stream; 19 KB with symbol staging) / 10 KB per wave
     uint32_t gt_rows[ONLY ? 1 : WAVES][512];                                   // DevTables.gather row of the current type, re-coded
     DqLich   lich_row[96];
 };
@@ -351,8 +366,8 @@ struct alignas(16) DqShared {
 // work != nullptr: lists per type (work[3][cap], nwork[3]; ONLY == 2 takes the stream list, ONLY == 0 all of them or,
 // with skip_stream, all but the stream list); else (ONLY == 0) plain batch: frame i of n_plain, type from types[i],
 // record i.
-template <int ONLY, int WAVES>
-__device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES> &sh, int wg, int n_wg,
+template <int ONLY, int WAVES, int NSYM = 0>
+__device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES, NSYM> &sh, int wg, int n_wg,
                    const float *__restrict__ fsym, const int32_t *__restrict__ work,
                    const int32_t *__restrict__ nwork, int cap,
                    const uint8_t *__restrict__ types, int n_plain,
@@ -360,7 +375,7 @@ __device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES> &sh, int 
                    const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr, int skip_stream,
                    int slot_floats, bool spectator = false)
 {
-    using Frame = QuadFrameT<(ONLY == 2) ? DQ_DECW_STREAM : DQ_DECW>;
+    using Frame = QuadFrameT<(ONLY == 2) ? DQ_DECW_STREAM : DQ_DECW, NSYM>;
     const int lane = lane_id(), q = lane >> 2, j = lane & 3, wave = (int)(threadIdx.x >> 6);
     Frame &F = sh.fr[wave][q];
     uint32_t *gt_row = sh.gt_rows[ONLY ? 0 : wave];
@@ -446,7 +461,7 @@ __device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES> &sh, int 
         const uint32_t r0_keep = work ? reinterpret_cast<const uint32_t *>(rec)[0] : (uint32_t)qtype;
         STAMP(0);
         if (ONLY) {
-            decode_quad_pass<Frame::kDecw, ONLY>(F, gs, gt_row, lich_row, ONLY, j, active, r0_keep, rec, C1, C2, genc, gerr, acc_, last_);
+            decode_quad_pass<Frame::kDecw, ONLY, NSYM>(F, gs, gt_row, lich_row, ONLY, j, active, r0_keep, rec, C1, C2, genc, gerr, acc_, last_);
         } else {
 #pragma unroll 1
             for (int pass = 0; pass < 3; ++pass) {
@@ -457,7 +472,7 @@ __device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES> &sh, int 
                     row_type = type;
                     wave_fence();
                 }
-                decode_quad_pass<Frame::kDecw, 0>(F, gs, gt_row, lich_row, type, j, active && qtype == type, r0_keep, rec, C1, C2, genc, gerr, acc_, last_);
+                decode_quad_pass<Frame::kDecw, 0, NSYM>(F, gs, gt_row, lich_row, type, j, active && qtype == type, r0_keep, rec, C1, C2, genc, gerr, acc_, last_);
             }
         }
         STAMP(5);
@@ -501,6 +516,24 @@ void k_decode_lists(const float *__restrict__ fsym, const int32_t *__restrict__ 
     } else {
         decode_quad_body<2, 4>(sh.s, (int)blockIdx.x - n_other, (int)gridDim.x - n_other, fsym, work, nwork, cap, nullptr, 0,
                                recs, genc, gerr, 0, slot_floats);
+    }
+}
+
+// slot_impl 1 (round 5, the round-4 review's item 4): the same launch for PLAIN stream slots -- the framer stores a stream
+// frame as its 192 symbols (768 B instead of 1,600), the stream role stages them in LDS (19 KB per wave: two workgroups
+// per CU instead of five) and gathers there.
+__global__ __launch_bounds__(256, 2)
+void k_decode_lists_p(const float *__restrict__ fsym, const int32_t *__restrict__ work,
+                      const int32_t *__restrict__ nwork, int cap, m17gpu_rec_dev *__restrict__ recs,
+                      const uint16_t *__restrict__ genc, const uint16_t *__restrict__ gerr, int slot_floats, int n_other)
+{
+    __shared__ union U { DqShared<2, 4, kFrameSyms> s; DqShared<0, 2> o; __device__ U() {} } sh;
+    if ((int)blockIdx.x < n_other) {
+        decode_quad_body<0, 2>(sh.o, (int)blockIdx.x, n_other, fsym, work, nwork, cap, nullptr, 0, recs, genc, gerr, 1, slot_floats,
+                               threadIdx.x >= 128);
+    } else {
+        decode_quad_body<2, 4, kFrameSyms>(sh.s, (int)blockIdx.x - n_other, (int)gridDim.x - n_other, fsym, work, nwork, cap, nullptr, 0,
+                                           recs, genc, gerr, 0, slot_floats);
     }
 }
 

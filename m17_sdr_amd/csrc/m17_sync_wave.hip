@@ -267,12 +267,12 @@ __device__ __forceinline__ void wv_framer_block(WvCtl &t, WvOut &o, const int n,
                     if (t.ferr > 5) { flags |= M17_F_LOST; unlock = true; }
                     else parse = true;
                 }
-                if (parse && o.mode == 1) flags |= M17_F_PARSED;
+                if (parse && (o.mode & 1)) flags |= M17_F_PARSED;
                 const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(t.ferr & 0xFF) << 24);
                 emit_record_wave(o.crecs, o.rec_cap, t.nrec, gl, w0, flags, r.variance, t.block_count, (uint32_t)(pos - 1));
                 if ((flags & M17_F_PARSED) && t.nrec < o.rec_cap && r.type >= 1 && r.type <= 3) {
                     float *fd = o.fsym_chan + (size_t)t.nrec * kSlotFloats;
-                    store_frame_slot_wave(fd, r.type, gl, rg.w, fs, hb);
+                    store_frame_slot_wave(fd, (o.mode & 16) ? 1 : r.type, gl, rg.w, fs, hb);     // mode bit 4 (slot_impl 1): every frame as its 192 symbols
                 }
                 t.nrec++;
                 if (unlock) {

@@ -56,6 +56,8 @@ struct m17gpu_ctx {
     int sync_impl = 0;                       // 0 | 6 = timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond (default);
                                              // 7 = wave per channel at every size
     int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
+    int slot_impl = 0;                       // stream frame slots: 1 = plain (768 B, regrouped in the decoder's LDS), 2 = regrouped by the framer (1,600 B),
+                                             // 0 = by path: plain behind the wave-per-channel FIR stage, regrouped behind front end + timing kernel
     int32_t *d_flags = nullptr;              // [n_flags] verdict words of m17gpu_shard_gather_packed
     int n_flags = 0;
     int fir_impl = 0;                        // 0 | 1 = front end + timing kernel (default); 2 = the fused FIR-stage kernel (m17_fused.hip:
@@ -193,6 +195,7 @@ int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc,
     return M17GPU_OK;
 }
 
+bool plain_slots(const m17gpu_ctx *ctx, int nblk);
 int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int nblk, int mode,
                       m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, float *d_syms, int32_t *d_nsyms,
                       hipStream_t st, int ext_lock = -1, int b0 = 0, int bcount = -1, int c0 = 0, int cn = -1)
@@ -210,7 +213,8 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
     // two-wave kernel (timing wave + framer wave per channel, m17_sync_duo.hip: one 8-wave workgroup per CU) up to
     // 1,024 channels -- a second workgroup per CU does not fit its registers; beyond that, and for the lock-forced
     // stage entry, which has no framer, one wave per channel with scalar control (m17_sync_wave.hip)
-    const bool duo = (ctx->sync_impl == 0 || ctx->sync_impl == 6) && ctx->C <= 1024 && ext_lock < 0;
+    const bool duo = (ctx->sync_impl == 0 || ctx->sync_impl == 6) && ctx->C <= 1024 && ext_lock < 0 && ctx->slot_impl != 1;
+    const int kmode = mode | ((!duo && plain_slots(ctx, nblk)) ? 16 : 0);       // bit 4: plain frame slots (wave kernels only)
     if (duo)
         hipLaunchKernelGGL(k_sync_frame_duo, dim3(cdiv(cn, 4)), dim3(512), 0, st,
                            disc, offs, state, cn, nblk, mode, recs, recs ? rec_cap : 0,
@@ -220,7 +224,7 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
         // 7 = round 3's form (all 62 tap registers, six waves per SIMD), 9 = the half-register form at six waves per SIMD
         auto kern = ctx->sync_impl == 7 ? k_sync_frame_wave<0, 6> : ctx->sync_impl == 9 ? k_sync_frame_wave<1, 6> : k_sync_frame_wave<1, 8>;
         hipLaunchKernelGGL(kern, dim3(cdiv(cn, WV_WAVES)), dim3(64 * WV_WAVES), 0, st,
-                           disc, offs, state, cn, nblk, mode, ext_lock, recs, recs ? rec_cap : 0,
+                           disc, offs, state, cn, nblk, kmode, ext_lock, recs, recs ? rec_cap : 0,
                            counts, syms, nsyms, fsym, b0, bcount);
     }
     HIPCHK(hipGetLastError());
@@ -233,6 +237,16 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
 // sixteen-block groups (its front-end tiles are sixteen of a channel's own blocks) on batches that give the chip at least
 // two waves per slot (measured at 16,384 channels: -8 % on the full chain at 16 blocks per call, +8 % at 12; nothing
 // at 4,096) -- and front end + timing kernel otherwise.
+int fir_choice(const m17gpu_ctx *ctx, int nblk);
+// Stream frames as their 192 symbols (slot_impl 1) or regrouped into decoder order by the framer (2)?  Measured at 16,384
+// channels (profiles/r05_plain_frame_slots.txt): the regrouped store costs the framer more than it saves the decoder when
+// framer and front end share their waves (k_rx_chan6: -6 % on that kernel, +15 % on the decoder, -1.3 % on the step) and
+// is worth its cost behind the stand-alone timing kernel (step +-1 %).  Only the wave-per-channel framers write plain slots.
+bool plain_slots(const m17gpu_ctx *ctx, int nblk)
+{
+    if (ctx->slot_impl) return ctx->slot_impl == 1;
+    return fir_choice(ctx, nblk) >= 3;
+}
 int fir_choice(const m17gpu_ctx *ctx, int nblk)
 {
     if (ctx->afc) return 1;
@@ -243,6 +257,7 @@ int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gp
                  int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st)
 {
     const int fir = fir_choice(ctx, nblk);
+    mode |= plain_slots(ctx, nblk) ? 16 : 0;                         // bit 4: plain frame slots
     if (fir == 4) {
         // the same built for six waves per SIMD (k_rx_chan6)
         hipLaunchKernelGGL(k_rx_chan6, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
@@ -267,7 +282,7 @@ int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gp
 // demap / gather / Viterbi / Golay of the frames the framer queued, then the per-channel in-order bookkeeping,
 // for the channel range [c0, c0 + cn): its own work lists and counters (slot numbers are relative to the range)
 int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, hipStream_t st,
-                  int c0, int cn, int chunk, hipEvent_t ev_mid)
+                  int c0, int cn, int chunk, hipEvent_t ev_mid, bool plain)
 {
     m17gpu_rec_dev *recs = reinterpret_cast<m17gpu_rec_dev *>(d_recs) + (size_t)c0 * rec_cap;
     int32_t *cnt = (d_counts ? d_counts : ctx->d_counts) + c0;
@@ -284,6 +299,12 @@ int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_c
     if (n_other > 512) n_other = 512;
     int grid = cdiv(tasks, 4);
     if (grid > 256 * 5) grid = 256 * 5;             // (four or three workgroups per CU: 0.177-0.180 -> 0.196-0.200 / 0.191 ms, round 4)
+    if (plain) {
+        int gp = cdiv(tasks, 4);
+        if (gp > 256 * 2) gp = 256 * 2;             // 76 KB of LDS per workgroup: two per CU
+        hipLaunchKernelGGL(k_decode_lists_p, dim3(gp + n_other), dim3(256), 0, st, fsym, work, nwork, (int)slots, recs,
+                           ctx->d_genc, ctx->d_gerr, kSlotFloats, n_other);
+    } else
     hipLaunchKernelGGL(k_decode_lists, dim3(grid + n_other), dim3(256), 0, st, fsym, work, nwork, (int)slots, recs,
                        ctx->d_genc, ctx->d_gerr, kSlotFloats, n_other);
     HIPCHK(hipGetLastError());
@@ -432,7 +453,7 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
             MARK(2);
         }
         if (full) {
-            if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, st, 0, ctx->C, 0, ev ? ev[3] : nullptr)) != M17GPU_OK) return rc;
+            if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, st, 0, ctx->C, 0, ev ? ev[3] : nullptr, plain_slots(ctx, nblk))) != M17GPU_OK) return rc;
             MARK(4);
         }
 #undef MARK
@@ -541,6 +562,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 4) return bad(); ctx->fe_impl = value; }
     else if (!std::strcmp(name, "fir_impl")) { if (value < 0 || value > 4) return bad(); ctx->fir_impl = value; }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
+    else if (!std::strcmp(name, "slot_impl")) { if (value < 0 || value > 2) return bad(); ctx->slot_impl = value; }
 
 #ifdef M17_STAMPS
     else if (!std::strcmp(name, "fe_debug")) { ctx->fe_debug = value; }      // instrumented build only: WRONG results
