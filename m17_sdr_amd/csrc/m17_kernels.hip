@@ -546,6 +546,10 @@ __device__ __forceinline__ void fe_convert(const uint32_t *w, v2f *z)
     for (int p = 0; p < N / 2; ++p) { z[2 * p] = x[2 * p] * (v2f){G[p].x, G[p].x}; z[2 * p + 1] = x[2 * p + 1] * (v2f){G[p].y, G[p].y}; }
 }
 
+__device__ __forceinline__ float dpp_quad_rot(float v)        // quad lanes (0,1,2,3) read lanes (3,0,1,2)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x93, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float dpp_quad_left(float v)       // quad lanes (0,1,2,3) read lanes (0,0,1,2)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x90, 0xF, 0xF, true));
@@ -766,9 +770,9 @@ __device__ __forceinline__ void frontend_lite_tile(const uint4 *__restrict__ iq,
     };
     uint4 s0 = ld(g0), s1 = ld(g1);
 
-    float offset = 0.0f;                                      // the row's DC sum so far, in all four lanes of the quad
+    float tsum = 0.0f;                                        // TWICE the row's DC sum so far, in lane 3 of the quad
     float *dst = disc_raw + (size_t)cb * kDiscOut;
-    const bool sub0 = sub == 0;
+    const bool sub0 = sub == 0, is1 = sub == 1, is2 = sub == 2, is3 = sub == 3;
     float *orow = &myo[cbl * FL_STRIDE];
 
     auto chunk_body = [&](int chunk, auto c5tag) {
@@ -790,45 +794,53 @@ __device__ __forceinline__ void frontend_lite_tile(const uint4 *__restrict__ iq,
         v2f z[8];
         fe_convert<4>(&w[0], &z[0]);
         fe_convert<4>(&w[4], &z[4]);
-        v2f p0 = {dpp_row_shr1(z[7].x), dpp_row_shr1(z[7].y)};            // sample -1 of this lane's run
-        v2f p1 = {dpp_row_shr1(z[6].x), dpp_row_shr1(z[6].y)};            // sample -2
-        if (sub0) { p0 = (v2f){c0re, c0im}; p1 = (v2f){c1re, c1im}; }
-        c0re = dpp_quad_b3(z[7].x); c0im = dpp_quad_b3(z[7].y);
-        c1re = dpp_quad_b3(z[6].x); c1im = dpp_quad_b3(z[6].y);
-        float u[8];
+        // samples -1 and -2 of this lane's run: the left neighbour's last two; for sub 0 lane 3's of the PREVIOUS chunk,
+        // which the same rotation of that chunk left in c0 / c1 (one lane move and one select per component)
+        const v2f r0 = {dpp_quad_rot(z[7].x), dpp_quad_rot(z[7].y)}, r1 = {dpp_quad_rot(z[6].x), dpp_quad_rot(z[6].y)};
+        const v2f p0 = {sub0 ? c0re : r0.x, sub0 ? c0im : r0.y};
+        const v2f p1 = {sub0 ? c1re : r1.x, sub0 ? c1im : r1.y};
+        c0re = r0.x; c0im = r0.y; c1re = r1.x; c1im = r1.y;
+        // dsp_arctan_disc2 (m17_dsp.cpp:194-222): z0 = sample e-1, z1 = sample e-2;  u = (z0.re (im - z1.im) - z0.im (re - z1.re)) / 2.
+        // u2 = 2 u: the halving is applied to the picks and to the block's sum only.  Exact: every nonzero z component is
+        // >= 2^-16 in magnitude, every nonzero difference of two >= 2^-39, every product >= 2^-55 and every difference
+        // of products and partial sum of them a multiple of 2^-78 -- nothing comes near the subnormal range, where alone
+        // a scaling by two does not commute with rounding.
+        float u2[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            // dsp_arctan_disc2 (m17_dsp.cpp:194-222): z0 = sample e-1, z1 = sample e-2;  u = (z0.re (im - z1.im) - z0.im (re - z1.re)) / 2
             const v2f z0 = (e >= 1) ? z[e >= 1 ? e - 1 : 0] : p0;
             const v2f z1 = (e >= 2) ? z[e >= 2 ? e - 2 : 0] : (e == 1 ? p0 : p1);
             const v2f d = z[e] - z1;
             const v2f pr = d * (v2f){z0.y, z0.x};                          // (aa, bb)
-            u[e] = (pr.y - pr.x) * 0.5f;
+            u2[e] = pr.y - pr.x;
         }
-        // ---- strictly sequential DC sum (m17_dsp.cpp:211) through the quad
-        float T = offset;
+        // ---- strictly sequential DC sum (m17_dsp.cpp:211) through the quad: in step s the lane with sub == s adds its
+        // eight values to the sum its left neighbour finished in step s - 1; sub 0 starts from the sum lane 3 finished in
+        // the previous chunk.  The lane moves ride on the first add of every step (v_add_f32_dpp).
+        float T = dpp_quad_b3(tsum) + u2[0];
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) {
-            const float left = dpp_quad_left(T);
-            T = sub0 ? offset : left;
+        for (int e = 1; e < 8; ++e) T = T + u2[e];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) T = T + u[e];
+        for (int s_ = 1; s_ < 4; ++s_) {
+            T = dpp_quad_left(T) + u2[0];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) T = T + u2[e];
         }
-        offset = dpp_quad_b3(T);
-        // ---- count % 5 == 0 pick (m17_dsp.cpp:207-210): positions 32 C5 + 8 sub + e of the 160-sample period
+        tsum = T;
+        // ---- count % 5 == 0 pick (m17_dsp.cpp:207-210): positions 32 C5 + 8 sub + e of the 160-sample period; the lane's
+        // first pick is entry e0 = 4 - (first position % 5) = 4 - (2 C5 + 3 sub) % 5 (32 % 5 == 2, 8 % 5 == 3), its second
+        // e0 + 5 when e0 <= 2: compile-time per (C5, sub), selected by the three lane-class masks
         {
-            const int m = (2 * C5 + 3 * sub) % 5;              // (first position) % 5: 32 % 5 == 2, 8 % 5 == 3
-            const int e0 = 4 - m;                              // first pick of this lane's run; the second is e0 + 5 when e0 <= 2
+            constexpr int E0 = 4 - (2 * C5) % 5, E1 = 4 - (2 * C5 + 3) % 5, E2 = 4 - (2 * C5 + 6) % 5, E3 = 4 - (2 * C5 + 9) % 5;
+            float v0 = u2[E0], v1 = u2[E0 <= 2 ? E0 + 5 : 7];
+            v0 = is1 ? u2[E1] : v0;  v1 = is1 ? u2[E1 <= 2 ? E1 + 5 : 7] : v1;
+            v0 = is2 ? u2[E2] : v0;  v1 = is2 ? u2[E2 <= 2 ? E2 + 5 : 7] : v1;
+            v0 = is3 ? u2[E3] : v0;  v1 = is3 ? u2[E3 <= 2 ? E3 + 5 : 7] : v1;
+            const int e0 = 4 - (2 * C5 + 3 * sub) % 5;
             const int o0 = (C5 * 32 + 8 * sub + e0) / 5;       // its output index within the period
-            const unsigned long long k0 = __builtin_amdgcn_ballot_w64(e0 == 0), k1 = __builtin_amdgcn_ballot_w64(e0 == 1),
-                                     k2 = __builtin_amdgcn_ballot_w64(e0 == 2), k3 = __builtin_amdgcn_ballot_w64(e0 == 3);
-            float v0, v1;
-            asm("v_cndmask_b32 %0, %5, %4, %9\n\tv_cndmask_b32 %0, %0, %3, %8\n\tv_cndmask_b32 %0, %0, %2, %7\n\tv_cndmask_b32 %0, %0, %1, %6"
-                : "=&v"(v0) : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "s"(k0), "s"(k1), "s"(k2), "s"(k3));
-            asm("v_cndmask_b32 %0, %3, %2, %5\n\tv_cndmask_b32 %0, %0, %1, %4"
-                : "=&v"(v1) : "v"(u[5]), "v"(u[6]), "v"(u[7]), "s"(k0), "s"(k1));
-            orow[o0] = v0;
-            if (e0 <= 2) orow[o0 + 1] = v1;
+            const v2f h = (v2f){v0, v1} * (v2f){0.5f, 0.5f};
+            orow[o0] = h.x;
+            if (e0 <= 2) orow[o0 + 1] = h.y;
         }
     };
 
@@ -847,6 +859,7 @@ __device__ __forceinline__ void frontend_lite_tile(const uint4 *__restrict__ iq,
         }
         wave_lds_sync();
     }
+    const float offset = dpp_quad_b3(tsum) * 0.5f;
     if (sub0 && valid) {
         offs[cb] = offset / (float)kBlockSamples;
         if (update_state && blk == 0) {

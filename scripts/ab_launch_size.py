@@ -1,8 +1,11 @@
 """Stage times against blocks per launch, clock settled (bench.py's settle): the same continuous stream per channel cut
 into calls of nblk blocks.  Per option set: kernel times of a call, and the same scaled to 12 blocks.
-   python scripts/ab_launch_size.py C mode "nblk,nblk,..." ["name=v,name=v" | "-"] ..."""
+   [M17_LIB=libm17gpu_prev.so] [M17_EBN0=8] python scripts/ab_launch_size.py C mode "nblk,nblk,..." ["name=v,name=v" | "-"] ..."""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import m17_sdr_amd._lib as L_
+if os.environ.get("M17_LIB"):                      # another build of the library (same-box A/B of two builds)
+    L_.LIB_PATH = os.path.join(os.path.dirname(L_.LIB_PATH), os.environ["M17_LIB"])
 import m17_sdr_amd as m
 C, mode = int(sys.argv[1]), int(sys.argv[2])
 sizes = [int(x) for x in sys.argv[3].split(",")]
