@@ -48,6 +48,8 @@ struct alignas(16) QuadFrameT {
 };
 static_assert(sizeof(QuadFrameT<DQ_DECW>) == 16 * DQ_DECW + 8 * DQ_CHUNK + 16 && sizeof(QuadFrameT<DQ_DECW_STREAM>) == 16 * DQ_DECW_STREAM + 8 * DQ_CHUNK + 16, "QuadFrame layout");
 
+typedef float dq_f4 __attribute__((ext_vector_type(4)));
+
 template <int CTRL> __device__ __forceinline__ float dppf(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -148,7 +150,8 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW, NSYM> &F, cons
                                                  const DqLich *lich, int type_rt, int j, bool writeback, uint32_t r0_keep,
                                                  m17gpu_rec_dev *rec, const v2f (&C1)[2], const v2f (&C2)[2],
                                                  const uint16_t *genc, const uint16_t *gerr,
-                                                 unsigned long long *acc_, unsigned long long &last_)
+                                                 unsigned long long *acc_, unsigned long long &last_,
+                                                 const float *__restrict__ gs_next, dq_f4 (&pre)[NSYM ? NSYM / 16 : 1])
 {
     const int type = TYPE_CT ? TYPE_CT : type_rt;
     const int steps = (type == 1) ? 244 : (type == 2 ? 148 : 210);       // DevTables.glen / 2
@@ -162,14 +165,13 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW, NSYM> &F, cons
     constexpr bool REGROUPED = (TYPE_CT == 2) && NSYM == 0;
     // slot_impl 1 (round 5, NSYM == 192): the slot holds the frame's 192 symbols as the framer has them (768 B instead of the
     // regrouped 1,600); the quad copies them into LDS in one contiguous read and every gather below goes there
+    // The loads are one TASK ahead (pre[]: this frame's symbols, requested during the previous task's forward pass by the
+    // caller's first request or by the request below): at the two waves per SIMD the staging leaves, nothing else would
+    // cover the round trip to memory at the head of every task.
     const float *gs = gs_in;
     if constexpr (NSYM != 0) {
-        const float4 *g4 = reinterpret_cast<const float4 *>(gs_in) + (NSYM / 16) * j;
-        float4 t[NSYM / 16];
 #pragma unroll
-        for (int r = 0; r < NSYM / 16; ++r) t[r] = g4[r];
-#pragma unroll
-        for (int r = 0; r < NSYM / 16; ++r) reinterpret_cast<float4 *>(F.sym)[(NSYM / 16) * j + r] = t[r];
+        for (int r = 0; r < NSYM / 16; ++r) reinterpret_cast<dq_f4 *>(F.sym)[(NSYM / 16) * j + r] = pre[r];
         wave_fence();
         gs = F.sym;
     }
@@ -254,21 +256,30 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW, NSYM> &F, cons
     // the decision enters the nibble through the carry of dw + dw.  Written out so that every step is exactly these
     // five instructions per state (the compiler's own choice was ~9, with packed adds fed by eight v_mov_dpp).
     // DPP reads need their source two instructions old: every source here was written at least five earlier.
-#define DQ_ACS(nw, pa, pb, PERM, M) do { float tb_;                                                      \
-        asm volatile("v_add_f32_dpp %0, %3, %5 quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"       \
-                     "v_sub_f32_dpp %1, %4, %5 quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"       \
+#define DQ_ACS_(nw, pa, pb, PERM, M, OPA, OPB) do { float tb_;                                            \
+        asm volatile(OPA " %0, %3, %5 quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"                \
+                     OPB " %1, %4, %5 quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"                \
                      "v_cmp_ngt_f32 vcc, %0, %1\n\t"                                                    \
                      "v_cndmask_b32 %0, %0, %1, vcc\n\t"                                                \
                      "v_addc_co_u32 %2, vcc, %2, %2, vcc"                                                \
                      : "=&v"(nw), "=&v"(tb_), "+v"(dw) : "v"(pa), "v"(pb), "v"(M) : "vcc"); } while (0)
+#define DQ_ACS_P(nw, pa, pb, PERM, M) DQ_ACS_(nw, pa, pb, PERM, M, "v_add_f32_dpp", "v_sub_f32_dpp")    /* metric +M */
+#define DQ_ACS_N(nw, pa, pb, PERM, M) DQ_ACS_(nw, pa, pb, PERM, M, "v_sub_f32_dpp", "v_add_f32_dpp")    /* metric -M */
+    // Branch metrics of the lane's four states (round 5): the code is linear, so the expected dibit of state 4j+i (even
+    // predecessor) is e(i) xor g(j) -- bm_even = ((j1 ^ i0) << 1) | (j1 ^ j0 ^ i1) -- and with m1' = sg1 m1, m2' = sg2 m2
+    // (sg = the lane's signs, those of its state 4j+3) the four metrics are -S, D, -D, S for i = 0..3, S = m1' + m2',
+    // D = m1' - m2': one multiply and one packed fma per step instead of two and two, the negations ride on the choice
+    // of add / subtract in the butterfly.  Same roundings: sg1 m1 is exact, fma(+-sg2, m2, sg1 m1) rounds the same exact
+    // sum the reference's (+-m1) + (+-m2) rounds (m17_conv.cpp:88-91), and -RN(x) = RN(-x).
 #define DQ_STEP(m1, m2, a0, a1, a2, a3, n0, n1, n2, n3) do {                                              \
-        const v2f mm1 = {m1, m1}, mm2 = {m2, m2};                                                       \
-        const v2f Ma = __builtin_elementwise_fma(C2[0], mm2, C1[0] * mm1);       /* states 4j, 4j+1 */   \
-        const v2f Mb = __builtin_elementwise_fma(C2[1], mm2, C1[1] * mm1);       /* states 4j+2, 4j+3 */ \
-        DQ_ACS(n3, a2, a3, "[1,3,1,3]", Mb.y);        /* descending: nibble bit i = decision of state 4j+i */ \
-        DQ_ACS(n2, a0, a1, "[1,3,1,3]", Mb.x);                                                          \
-        DQ_ACS(n1, a2, a3, "[0,2,0,2]", Ma.y);                                                          \
-        DQ_ACS(n0, a0, a1, "[0,2,0,2]", Ma.x); } while (0)
+        const float t1_ = sg1 * (m1);                                                                   \
+        const v2f SD = __builtin_elementwise_fma(K2, (v2f){m2, m2}, (v2f){t1_, t1_});   /* (S, D) */    \
+        DQ_ACS_P(n3, a2, a3, "[1,3,1,3]", SD.x);      /* descending: nibble bit i = decision of state 4j+i */ \
+        DQ_ACS_N(n2, a0, a1, "[1,3,1,3]", SD.y);                                                        \
+        DQ_ACS_P(n1, a2, a3, "[0,2,0,2]", SD.y);                                                        \
+        DQ_ACS_N(n0, a0, a1, "[0,2,0,2]", SD.x); } while (0)
+    const float sg1 = C1[1].y;
+    const v2f K2 = {C2[1].y, -C2[1].y};
     commit_chunk(0);
     wave_fence();
     asm volatile("s_nop 1");
@@ -288,6 +299,15 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW, NSYM> &F, cons
         }
         wave_fence();
         if (type == 2 && c0 == 0) gerr_v = gerr[gpar ^ genc_v];        // second Golay table: consumed after the traceback
+        if constexpr (NSYM != 0) {
+            // the next task's symbols: requested behind the Golay reads (loads return in order: a wait for an earlier
+            // request never waits for these), consumed at the head of the next pass
+            if (c0 == 0 && gs_next) {
+                const dq_f4 *g4 = reinterpret_cast<const dq_f4 *>(gs_next) + (NSYM / 16) * j;
+#pragma unroll
+                for (int r = 0; r < NSYM / 16; ++r) pre[r] = g4[r];
+            }
+        }
         if (c0 + DQ_CHUNK < steps) { commit_chunk(c0 + DQ_CHUNK); wave_fence(); }
         STAMP(3);
     }
@@ -442,6 +462,14 @@ __device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES, NSYM> &sh
     int task = wg * WAVES + wave;
     int slot_next = 0;
     if (work && task < ntask) { int qt; bool ac; slot_next = work[pick(task, qt, ac)]; }
+    dq_f4 pre[NSYM ? NSYM / 16 : 1];                                        // plain slots: the symbols of the task to come
+    if constexpr (NSYM != 0) {
+        if (task < ntask) {
+            const dq_f4 *g4 = reinterpret_cast<const dq_f4 *>(fsym + (size_t)slot_next * slot_floats) + (NSYM / 16) * j;
+#pragma unroll
+            for (int r = 0; r < NSYM / 16; ++r) pre[r] = g4[r];
+        }
+    }
     for (; task < ntask; task += stride) {
         STAMP(6);
         // ---- which frame (the work-list entry was requested one task ahead)
@@ -461,7 +489,9 @@ __device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES, NSYM> &sh
         const uint32_t r0_keep = work ? reinterpret_cast<const uint32_t *>(rec)[0] : (uint32_t)qtype;
         STAMP(0);
         if (ONLY) {
-            decode_quad_pass<Frame::kDecw, ONLY, NSYM>(F, gs, gt_row, lich_row, ONLY, j, active, r0_keep, rec, C1, C2, genc, gerr, acc_, last_);
+            const float *gs_next = (NSYM != 0 && task + stride < ntask) ? fsym + (size_t)slot_next * slot_floats : nullptr;
+            decode_quad_pass<Frame::kDecw, ONLY, NSYM>(F, gs, gt_row, lich_row, ONLY, j, active, r0_keep, rec, C1, C2, genc, gerr, acc_, last_,
+                                                       gs_next, pre);
         } else {
 #pragma unroll 1
             for (int pass = 0; pass < 3; ++pass) {
@@ -472,7 +502,8 @@ __device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES, NSYM> &sh
                     row_type = type;
                     wave_fence();
                 }
-                decode_quad_pass<Frame::kDecw, 0, NSYM>(F, gs, gt_row, lich_row, type, j, active && qtype == type, r0_keep, rec, C1, C2, genc, gerr, acc_, last_);
+                decode_quad_pass<Frame::kDecw, 0, NSYM>(F, gs, gt_row, lich_row, type, j, active && qtype == type, r0_keep, rec, C1, C2, genc, gerr, acc_, last_,
+                                                        nullptr, pre);
             }
         }
         STAMP(5);

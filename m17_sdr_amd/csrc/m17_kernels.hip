@@ -596,9 +596,9 @@ __device__ __forceinline__ void frontend_tile(const uint4 *__restrict__ iq, Chan
     };
     uint4 s0 = ld(g0), s1 = ld(g1), s2 = ld(g2), s3 = ld(g3);
 
-    float offset = 0.0f;                                      // the row's DC sum so far, in all four lanes of the quad
+    float tsum = 0.0f;                                        // TWICE the row's DC sum so far, in lane 3 of the quad
     float *dst = disc_raw + (size_t)cb * kDiscOut;
-    const bool sub0 = sub == 0;
+    const bool sub0 = sub == 0, is1 = sub == 1, is2 = sub == 2, is3 = sub == 3;
     float *orow = &myo[cbl * FQ_STRIDE];
 
     auto chunk_body = [&](int chunk, auto c5tag) {
@@ -625,51 +625,50 @@ __device__ __forceinline__ void frontend_tile(const uint4 *__restrict__ iq, Chan
         v2f z[16];
 #pragma unroll
         for (int e = 0; e < 16; e += FE_GROUP) fe_convert<FE_GROUP>(&w[e], &z[e]);
-        v2f p0 = {dpp_row_shr1(z[15].x), dpp_row_shr1(z[15].y)};          // sample -1 of this lane's run
-        v2f p1 = {dpp_row_shr1(z[14].x), dpp_row_shr1(z[14].y)};          // sample -2
-        if (sub0) { p0 = (v2f){c0re, c0im}; p1 = (v2f){c1re, c1im}; }
-        c0re = dpp_quad_b3(z[15].x); c0im = dpp_quad_b3(z[15].y);
-        c1re = dpp_quad_b3(z[14].x); c1im = dpp_quad_b3(z[14].y);
-        float u[16];
+        // samples -1 and -2 of this lane's run: the left neighbour's last two; for sub 0 lane 3's of the PREVIOUS chunk,
+        // which the same rotation of that chunk left in c0 / c1 (one lane move and one select per component)
+        const v2f r0 = {dpp_quad_rot(z[15].x), dpp_quad_rot(z[15].y)}, r1 = {dpp_quad_rot(z[14].x), dpp_quad_rot(z[14].y)};
+        const v2f p0 = {sub0 ? c0re : r0.x, sub0 ? c0im : r0.y};
+        const v2f p1 = {sub0 ? c1re : r1.x, sub0 ? c1im : r1.y};
+        c0re = r0.x; c0im = r0.y; c1re = r1.x; c1im = r1.y;
+        // dsp_arctan_disc2 (m17_dsp.cpp:194-222): z0 = sample e-1, z1 = sample e-2;  u = (z0.re (im - z1.im) - z0.im (re - z1.re)) / 2.
+        // u2 = 2 u: the halving is applied to the picks and to the block's sum only (exact: see frontend_lite_tile)
+        float u2[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            // dsp_arctan_disc2 (m17_dsp.cpp:194-222): z0 = sample e-1, z1 = sample e-2;  u = (z0.re (im - z1.im) - z0.im (re - z1.re)) / 2
             const v2f z0 = (e >= 1) ? z[e >= 1 ? e - 1 : 0] : p0;
             const v2f z1 = (e >= 2) ? z[e >= 2 ? e - 2 : 0] : (e == 1 ? p0 : p1);
             const v2f d = z[e] - z1;
             const v2f pr = d * (v2f){z0.y, z0.x};                          // (aa, bb)
-            u[e] = (pr.y - pr.x) * 0.5f;
+            u2[e] = pr.y - pr.x;
         }
-        // ---- strictly sequential DC sum (m17_dsp.cpp:211) through the quad
-        float T = offset;
+        // ---- strictly sequential DC sum (m17_dsp.cpp:211) through the quad; the lane moves ride on the first add of every step
+        float T = dpp_quad_b3(tsum) + u2[0];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float left = dpp_quad_left(T);
-            T = sub0 ? offset : left;
+        for (int e = 1; e < 16; ++e) T = T + u2[e];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) T = T + u[e];
+        for (int s = 1; s < 4; ++s) {
+            T = dpp_quad_left(T) + u2[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) T = T + u2[e];
         }
-        offset = dpp_quad_b3(T);
-        // ---- count % 5 == 0 pick (m17_dsp.cpp:207-210): positions C5 * 64 + 16 sub + e of the 320-sample period
+        tsum = T;
+        // ---- count % 5 == 0 pick (m17_dsp.cpp:207-210): positions 64 C5 + 16 sub + e of the 320-sample period; the lane's
+        // first pick is entry e0 = 4 - (first position % 5) = 4 - (4 C5 + sub) % 5 (64 % 5 == 4, 16 % 5 == 1), then e0 + 5,
+        // e0 + 10 (and 15 when e0 == 0): compile-time per (C5, sub), selected by the three lane-class masks
         {
-            const int m = (C5 * 4 + sub) % 5;                  // (first position) % 5: 64 % 5 == 4, 16 % 5 == 1
-            const int e0 = 4 - m;                              // first pick of this lane's run
-            const int o0 = (C5 * 64 + 16 * sub) / 5;           // its output index within the period (position e0 is the one with % 5 == 4)
-            // selects as v_cndmask on lane masks (left to itself the compiler builds a five-way divergent switch)
-            const unsigned long long k0 = __builtin_amdgcn_ballot_w64(e0 == 0), k1 = __builtin_amdgcn_ballot_w64(e0 == 1),
-                                     k2 = __builtin_amdgcn_ballot_w64(e0 == 2), k3 = __builtin_amdgcn_ballot_w64(e0 == 3);
-            auto sel5 = [&](float a0, float a1, float a2, float a3, float a4) {
-                float r;
-                asm("v_cndmask_b32 %0, %5, %4, %9\n\tv_cndmask_b32 %0, %0, %3, %8\n\tv_cndmask_b32 %0, %0, %2, %7\n\tv_cndmask_b32 %0, %0, %1, %6"
-                    : "=&v"(r) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "s"(k0), "s"(k1), "s"(k2), "s"(k3));
-                return r;
-            };
-            const float v0 = sel5(u[0], u[1], u[2], u[3], u[4]), v1 = sel5(u[5], u[6], u[7], u[8], u[9]),
-                        v2 = sel5(u[10], u[11], u[12], u[13], u[14]);
-            orow[o0] = v0;
-            orow[o0 + 1] = v1;
-            orow[o0 + 2] = v2;
-            if (e0 == 0) orow[o0 + 3] = u[15];
+            constexpr int E0 = 4 - (4 * C5) % 5, E1 = 4 - (4 * C5 + 1) % 5, E2 = 4 - (4 * C5 + 2) % 5, E3 = 4 - (4 * C5 + 3) % 5;
+            float v0 = u2[E0], v1 = u2[E0 + 5], v2 = u2[E0 + 10];
+            v0 = is1 ? u2[E1] : v0;  v1 = is1 ? u2[E1 + 5] : v1;  v2 = is1 ? u2[E1 + 10] : v2;
+            v0 = is2 ? u2[E2] : v0;  v1 = is2 ? u2[E2 + 5] : v1;  v2 = is2 ? u2[E2 + 10] : v2;
+            v0 = is3 ? u2[E3] : v0;  v1 = is3 ? u2[E3 + 5] : v1;  v2 = is3 ? u2[E3 + 10] : v2;
+            const int e0 = 4 - (C5 * 4 + sub) % 5;
+            const int o0 = (C5 * 64 + 16 * sub) / 5;           // output index of the first pick within the period (position e0 is the one with % 5 == 4)
+            const v2f h01 = (v2f){v0, v1} * (v2f){0.5f, 0.5f}, h23 = (v2f){v2, u2[15]} * (v2f){0.5f, 0.5f};
+            orow[o0] = h01.x;
+            orow[o0 + 1] = h01.y;
+            orow[o0 + 2] = h23.x;
+            if (e0 == 0) orow[o0 + 3] = h23.y;
         }
     };
 
@@ -688,6 +687,7 @@ __device__ __forceinline__ void frontend_tile(const uint4 *__restrict__ iq, Chan
         }
         wave_lds_sync();
     }
+    const float offset = dpp_quad_b3(tsum) * 0.5f;
     if (sub0 && valid) {
         offs[cb] = offset / (float)kBlockSamples;
         if (update_state && blk == 0) {

@@ -154,6 +154,11 @@ static void build(Tables &T)
         T.bm_even[v] = (uint8_t)((T.clut[2 * v][0] << 1) | T.clut[2 * v][1]);
         T.bm_odd[v]  = (uint8_t)((T.clut[2 * v + 1][0] << 1) | T.clut[2 * v + 1][1]);
     }
+    // the quad decoder's branch metrics (m17_decode_quad.hip, DQ_STEP) rest on this separation of bm_even
+    for (int v = 0; v < 16; ++v) {
+        const int j = v >> 2, i = v & 3;
+        if (T.bm_even[v] != (((((j >> 1) ^ i) & 1) << 1) | (((j >> 1) ^ j ^ (i >> 1)) & 1))) std::abort();
+    }
 }
 
 // Pluto receive decimator taps (radio.cpp:45-51): rectangular-window low-pass of
