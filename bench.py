@@ -282,7 +282,8 @@ def roofline_obj(kms, ncalls, mode, cb_per_launch, key):
         # and framer of a channel in one wave): there is no front-end launch, the first interval is the gap between two events
         kms[1] += kms[0]
         kms[0] = 0.0
-        names[1] = "k_rx_chan6"
+        # ... or, up to 1,024 channels, front end, timing loop and framer of a channel on three waves of one workgroup
+        names[1] = "k_rx_chan6" if int(key.split(":")[1].split("x")[0]) > 1024 else "k_sync_frame_duo<1>"
     used = [i for i in range(4) if kms[i] > 0.002]
     t_path_ms = sum(kms[i] for i in used)
     dom = max(used, key=lambda i: kms[i]) if used else 0

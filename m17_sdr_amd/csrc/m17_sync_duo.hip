@@ -1,5 +1,6 @@
 // m17_sync_duo.hip -- k_sync_frame_duo: timing recovery and framer of one channel on TWO waves
-// of the same workgroup, decoupled by one block (64 lanes per channel; used up to 1,024 channels).
+// of the same workgroup, decoupled by one block (64 lanes per channel; used up to 1,024 channels); as <1> with the
+// channel's front end on a third (the FIR stage of small batches as one pipelined kernel).
 //
 // Reference: m17_rx_sync_samples (m17_rx_sync.cpp:77-99), m17_rx_sym (m17_rx_frame.cpp:126-177).
 //
@@ -28,7 +29,8 @@ struct DuoChan {                               // LDS of one channel
     int   nsym[4];                             // symbols of block b at [b & 3]
     int   lock_after[4];                       // lock flag after the framer of block b at [b & 3]
     int   tim_blk, frm_blk;                    // blocks published / framed since b0
-    int   pad[6];
+    int   fe_rows;                             // PIPE: blocks since b0 whose discriminator rows the front-end wave has stored
+    int   pad[5];
 };
 
 // Mailbox words are read and written as LDS words (ds_read / ds_write), not through generic pointers: a
@@ -66,32 +68,55 @@ __device__ __forceinline__ void duo_post_lds(int *flag, int value, int lane)
     if (lane == 0) lds_poke(flag, value);
 }
 
-__global__ __launch_bounds__(512)
+// PIPE (round 5; k_rx_trio, option fir_impl 5): a THIRD wave per channel is the channel's front end -- sixteen of its
+// blocks per tile (frontend_tile), rows stored to the workspace and announced through fe_rows -- so the front end of
+// blocks 16 .. runs under the timing loop of blocks 0 .. instead of in a kernel in front of it.  At 1,024 channels
+// both kernels are latency-bound (one channel per SIMD slot, its blocks strictly in order): what the stand-alone front
+// end takes (0.10 of 0.24 ms at 1,024 x 50) is time in which no timing wave runs.  Same flag discipline as above: the
+// front-end wave waits for nothing, the timing wave waits only for rows the front-end wave is on its way to.
+template <int PIPE>
+__global__ __launch_bounds__(PIPE ? 768 : 512)
 void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                       const float *__restrict__ offs,     // [C][nblk] or null (already DC-free)
                       ChanState *__restrict__ st, int C, int nblk, int mode,
                       m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
                       float *__restrict__ syms, int32_t *__restrict__ nsyms,
-                      float *__restrict__ fsym, int b0, int bcount)
+                      float *__restrict__ fsym, int b0, int bcount,
+                      const uint4 *__restrict__ iq = nullptr, float *__restrict__ disc_w = nullptr, float *__restrict__ offs_w = nullptr)
 {
     constexpr int LPC = 64;
     __shared__ __attribute__((aligned(16))) float taps[kPhases * 64];      // (matched, derivative) pairs per branch
     __shared__ __attribute__((aligned(16))) DuoChan chs[4];
+    __shared__ __attribute__((aligned(16))) uint32_t fe_raw[PIPE ? 4 : 1][PIPE ? 16 * FQ_STRIDE : 4];
+    __shared__ __attribute__((aligned(16))) float fe_out[PIPE ? 4 : 1][PIPE ? 16 * FQ_STRIDE : 4];
     const int wave = (int)(threadIdx.x >> 6), gl = lane_id();
     const int w = wave & 3;
-    const bool is_framer = wave >= 4;
-    for (int q = (int)threadIdx.x; q < kPhases * 32; q += 512) {
+    const bool is_framer = (wave >> 2) == 1;
+    for (int q = (int)threadIdx.x; q < kPhases * 32; q += (PIPE ? 768 : 512)) {
         taps[2 * q] = (&c_tab.mf[0][0])[q];
         taps[2 * q + 1] = (&c_tab.md[0][0])[q];
     }
-    if (threadIdx.x < 4) { chs[threadIdx.x].tim_blk = 0; chs[threadIdx.x].frm_blk = 0; }
+    if (threadIdx.x < 4) { chs[threadIdx.x].tim_blk = 0; chs[threadIdx.x].frm_blk = 0; chs[threadIdx.x].fe_rows = 0; }
     __syncthreads();                                    // the only workgroup barrier
     const int chan = (int)blockIdx.x * 4 + w;
-    if (chan >= C) return;                              // both waves of the channel leave together
+    if (chan >= C) return;                              // all waves of the channel leave together
     DuoChan &my = chs[w];
     ChanState &cs = st[chan];
     const int bend = b0 + bcount;
     int *tim_blk = &my.tim_blk, *frm_blk = &my.frm_blk;
+    if constexpr (PIPE) {
+        if (wave >= 8) {
+            // =========================== front-end wave ===========================
+            for (int r0 = 0; r0 < bcount; r0 += 16) {
+                frontend_tile(iq, st, disc_w, offs_w, nblk, 1,
+                              [&](int i, bool &valid) { valid = r0 + i < bcount; return chan * nblk + b0 + (valid ? r0 + i : bcount - 1); },
+                              fe_raw[w], fe_out[w], gl);
+                duo_post(&my.fe_rows, min(r0 + 16, bcount), gl);
+            }
+            return;
+        }
+    }
+    int fe_seen = PIPE ? 0 : 0x7FFFFFFF;               // rows known to be there (timing wave)
 
 #ifdef M17_STAMPS
     unsigned long long acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, last_ = __builtin_amdgcn_s_memtime();
@@ -106,6 +131,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
         for (int q = gl; q < kTaps - 1; q += LPC) my.x[q] = cs.buff[q + 1];
         const float *dsrc = disc + (size_t)chan * nblk * kDiscOut;
         const float *osrc = offs ? offs + (size_t)chan * nblk : nullptr;
+        if constexpr (PIPE) { duo_wait(&my.fe_rows, 1); fe_seen = lds_peek(&my.fe_rows); }
         {
             const float off = osrc ? osrc[b0] : 0.0f;
             for (int q = gl; q < kDiscOut; q += LPC) {
@@ -124,6 +150,9 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
             float pf[PF];
             float noff = 0.0f;
             if (b + 1 < bend) {
+                if constexpr (PIPE) {
+                    if (b + 1 - b0 >= fe_seen) { duo_wait(&my.fe_rows, b + 2 - b0); fe_seen = lds_peek(&my.fe_rows); }
+                }
                 const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
                 noff = osrc ? osrc[b + 1] : 0.0f;
 #pragma unroll

@@ -198,7 +198,8 @@ int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc,
 bool plain_slots(const m17gpu_ctx *ctx, int nblk);
 int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int nblk, int mode,
                       m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts, float *d_syms, int32_t *d_nsyms,
-                      hipStream_t st, int ext_lock = -1, int b0 = 0, int bcount = -1, int c0 = 0, int cn = -1)
+                      hipStream_t st, int ext_lock = -1, int b0 = 0, int bcount = -1, int c0 = 0, int cn = -1,
+                      const int16_t *pipe_iq = nullptr)
 {
     if (bcount < 0) bcount = nblk;
     if (cn < 0) cn = ctx->C;
@@ -215,10 +216,17 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
     // stage entry, which has no framer, one wave per channel with scalar control (m17_sync_wave.hip)
     const bool duo = (ctx->sync_impl == 0 || ctx->sync_impl == 6) && ctx->C <= 1024 && ext_lock < 0 && ctx->slot_impl != 1;
     const int kmode = mode | ((!duo && plain_slots(ctx, nblk)) ? 16 : 0);       // bit 4: plain frame slots (wave kernels only)
-    if (duo)
-        hipLaunchKernelGGL(k_sync_frame_duo, dim3(cdiv(cn, 4)), dim3(512), 0, st,
+    if (duo && pipe_iq)
+        // front end, timing loop and framer of a channel on three waves of one workgroup (k_sync_frame_duo<1>)
+        hipLaunchKernelGGL(k_sync_frame_duo<1>, dim3(cdiv(cn, 4)), dim3(768), 0, st,
                            disc, offs, state, cn, nblk, mode, recs, recs ? rec_cap : 0,
-                           counts, syms, nsyms, fsym, b0, bcount);
+                           counts, syms, nsyms, fsym, b0, bcount,
+                           reinterpret_cast<const uint4 *>(pipe_iq + (size_t)c0 * nblk * kBlockSamples * 2),
+                           const_cast<float *>(disc), const_cast<float *>(offs));
+    else if (duo)
+        hipLaunchKernelGGL(k_sync_frame_duo<0>, dim3(cdiv(cn, 4)), dim3(512), 0, st,
+                           disc, offs, state, cn, nblk, mode, recs, recs ? rec_cap : 0,
+                           counts, syms, nsyms, fsym, b0, bcount, nullptr, nullptr, nullptr);
     else {
         // default (0 / 6 beyond 1,024 channels, and 8): taps and window through half the registers, eight waves per SIMD;
         // 7 = round 3's form (all 62 tap registers, six waves per SIMD), 9 = the half-register form at six waves per SIMD
@@ -244,13 +252,21 @@ int fir_choice(const m17gpu_ctx *ctx, int nblk);
 // is worth its cost behind the stand-alone timing kernel (step +-1 %).  Only the wave-per-channel framers write plain slots.
 bool plain_slots(const m17gpu_ctx *ctx, int nblk)
 {
+    const int fir = fir_choice(ctx, nblk);
+    if (fir == 5) return false;                     // the two-wave framer writes regrouped slots only
     if (ctx->slot_impl) return ctx->slot_impl == 1;
-    return fir_choice(ctx, nblk) >= 3;
+    return fir == 3 || fir == 4;
 }
+// 5: front end, timing loop and framer of a channel on three waves of one workgroup (k_sync_frame_duo<1>) -- small
+// batches, where one channel per SIMD slot leaves both kernels latency-bound: up to 1,024 channels, calls of at least
+// sixteen blocks (the front-end wave's tile is sixteen of the channel's blocks; a shorter call would pay for a whole one)
 int fir_choice(const m17gpu_ctx *ctx, int nblk)
 {
     if (ctx->afc) return 1;
+    const bool trio_ok = (ctx->sync_impl == 0 || ctx->sync_impl == 6) && ctx->C <= 1024 && ctx->slot_impl != 1;
+    if (ctx->fir_impl == 5) return trio_ok ? 5 : 1;
     if (ctx->fir_impl != 0) return ctx->fir_impl;
+    if (trio_ok && nblk >= 16) return 5;
     return (nblk % 16 == 0 && ctx->C >= 8192) ? 4 : 1;
 }
 int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
@@ -441,6 +457,11 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
             }
             MARK(1);
             MARK(2);
+        } else if (fir_choice(ctx, nblk) == 5) {
+            MARK(1);                             // no separate front end: a third wave per channel, under the timing loop
+            if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
+                                        d_syms, d_nsyms, st, -1, 0, -1, 0, -1, d_iq)) != M17GPU_OK) return rc;
+            MARK(2);
         } else if (fir_choice(ctx, nblk) >= 2) {
             MARK(1);                             // no separate front end: stage 0 reads as zero, stage 1 is the fused kernel
             if ((rc = launch_fused(ctx, d_iq, nblk, mode, d_recs, rec_cap, d_counts, d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
@@ -560,7 +581,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     auto bad = [&]() { return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: value out of range for ") + name); };
     if (!std::strcmp(name, "sync_impl")) { if (value != 0 && (value < 6 || value > 9)) return bad(); ctx->sync_impl = value; }
     else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 4) return bad(); ctx->fe_impl = value; }
-    else if (!std::strcmp(name, "fir_impl")) { if (value < 0 || value > 4) return bad(); ctx->fir_impl = value; }
+    else if (!std::strcmp(name, "fir_impl")) { if (value < 0 || value > 5) return bad(); ctx->fir_impl = value; }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
     else if (!std::strcmp(name, "slot_impl")) { if (value < 0 || value > 2) return bad(); ctx->slot_impl = value; }
 

@@ -162,7 +162,7 @@ def test_exact_arithmetic_selftest():
 
 
 @pytest.mark.parametrize("options", [
-    {"sync_impl": 6}, {"sync_impl": 7}, {"sync_impl": 8}, {"sync_impl": 9}, {"fe_impl": 1}, {"fe_impl": 2}, {"fe_impl": 3}, {"fe_impl": 4}, {"fir_impl": 2}, {"fir_impl": 3}, {"fir_impl": 4}, {"fir_impl": 1, "sync_impl": 7}, {"slot_impl": 1}, {"slot_impl": 2}, {"slot_impl": 1, "fir_impl": 4}, {"slot_impl": 2, "fir_impl": 4}])
+    {"sync_impl": 6}, {"sync_impl": 7}, {"sync_impl": 8}, {"sync_impl": 9}, {"fe_impl": 1}, {"fe_impl": 2}, {"fe_impl": 3}, {"fe_impl": 4}, {"fir_impl": 1}, {"fir_impl": 2}, {"fir_impl": 3}, {"fir_impl": 4}, {"fir_impl": 5}, {"fir_impl": 5, "sync_impl": 6}, {"fir_impl": 1, "sync_impl": 7}, {"slot_impl": 1}, {"slot_impl": 2}, {"slot_impl": 1, "fir_impl": 4}, {"slot_impl": 2, "fir_impl": 4}])
 def test_every_kernel_variant_is_bit_exact(options):
     _rx_compare(C=40, nblk=22, mode=1, ebn0=200.0, nsf=12, options=options)
     _rx_compare(C=40, nblk=9, mode=1, ebn0=9.0, nsf=5, calls=3, options=options)
@@ -501,11 +501,11 @@ def test_set_option_rejects_unknown_and_out_of_range_values():
     import m17_sdr_amd as m
     rx = m.Receiver(2, 2)
     for name, value in (("fe_impl", 101), ("fe_impl", 107), ("fe_impl", -1), ("fe_impl", 5), ("sync_impl", 2),
-                        ("sync_impl", 5), ("sync_impl", 1), ("sync_impl", 4), ("sync_impl", 10), ("fir_impl", 5), ("fir_impl", -1), ("slot_impl", 3), ("overlap_chunks", 2), ("fe_waves_per_cu", 8), ("lanes_per_channel", 16),
+                        ("sync_impl", 5), ("sync_impl", 1), ("sync_impl", 4), ("sync_impl", 10), ("fir_impl", 6), ("fir_impl", -1), ("slot_impl", 3), ("overlap_chunks", 2), ("fe_waves_per_cu", 8), ("lanes_per_channel", 16),
                         ("decode_impl", 0), ("no_such_option", 1)):
         with pytest.raises(RuntimeError):
             rx.set_option(name, value)
-    for name, value in (("fe_impl", 0), ("fe_impl", 1), ("fe_impl", 2), ("fe_impl", 3), ("fe_impl", 4), ("sync_impl", 0), ("sync_impl", 6), ("sync_impl", 7), ("sync_impl", 8), ("sync_impl", 9), ("fir_impl", 0), ("fir_impl", 1), ("fir_impl", 2), ("fir_impl", 3), ("fir_impl", 4), ("slot_impl", 1), ("slot_impl", 2), ("slot_impl", 0)):
+    for name, value in (("fe_impl", 0), ("fe_impl", 1), ("fe_impl", 2), ("fe_impl", 3), ("fe_impl", 4), ("sync_impl", 0), ("sync_impl", 6), ("sync_impl", 7), ("sync_impl", 8), ("sync_impl", 9), ("fir_impl", 0), ("fir_impl", 1), ("fir_impl", 2), ("fir_impl", 3), ("fir_impl", 4), ("fir_impl", 5), ("slot_impl", 1), ("slot_impl", 2), ("slot_impl", 0)):
         rx.set_option(name, value)
     rx.close()
 
