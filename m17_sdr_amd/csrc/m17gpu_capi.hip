@@ -60,9 +60,11 @@ struct m17gpu_ctx {
                                              // 0 = by path: plain behind the wave-per-channel FIR stage, regrouped behind front end + timing kernel
     int32_t *d_flags = nullptr;              // [n_flags] verdict words of m17gpu_shard_gather_packed
     int n_flags = 0;
-    int fir_impl = 0;                        // 0 | 1 = front end + timing kernel (default); 2 = the fused FIR-stage kernel (m17_fused.hip:
+    int fir_impl = 0;                        // 0 = by call (fir_choice); 1 = front end + timing kernel; 2 = the fused FIR-stage kernel (m17_fused.hip:
                                              // measured 18 % slower at 16,384 x 12, kept under the parity tests); 3 = wave per channel
-                                             // over sixteen-row tiles of its own blocks, rows through the workspace (k_rx_chan)
+                                             // over sixteen-row tiles of its own blocks, rows through the workspace (k_rx_chan);
+                                             // 4 = the same at six waves per SIMD (k_rx_chan6); 5 = three waves per channel, the front end
+                                             // one of them (k_sync_frame_duo<1>, up to 1,024 channels)
     std::vector<hipEvent_t> ev_pool;         // 7 events per profiled call: 5 stage marks + call start / end
     std::vector<int> ev_mode;                // mode of each profiled call
 };
