@@ -68,6 +68,17 @@ __device__ __forceinline__ void duo_post_lds(int *flag, int value, int lane)
     if (lane == 0) lds_poke(flag, value);
 }
 
+// A block's DC offset.  PIPE: the offsets of thirty-two blocks share a 128-byte line, i.e. two front-end tiles do: a line this
+// wave read while only its first half had been written must not be served again from the CU's vector cache when the
+// second half is there -- the load is an agent-scope one (past that cache).  The discriminator rows need nothing of the
+// kind: a row is twelve whole lines, written before it is announced and read only after.
+template <int PIPE>
+__device__ __forceinline__ float duo_offs(const float *p)
+{
+    if constexpr (PIPE) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
 // PIPE (round 5; k_rx_trio, option fir_impl 5): a THIRD wave per channel is the channel's front end -- sixteen of its
 // blocks per tile (frontend_tile), rows stored to the workspace and announced through fe_rows -- so the front end of
 // blocks 16 .. runs under the timing loop of blocks 0 .. instead of in a kernel in front of it.  At 1,024 channels
@@ -133,7 +144,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
         const float *osrc = offs ? offs + (size_t)chan * nblk : nullptr;
         if constexpr (PIPE) { duo_wait(&my.fe_rows, 1); fe_seen = lds_peek(&my.fe_rows); }
         {
-            const float off = osrc ? osrc[b0] : 0.0f;
+            const float off = osrc ? duo_offs<PIPE>(&osrc[b0]) : 0.0f;
             for (int q = gl; q < kDiscOut; q += LPC) {
                 float v = dsrc[(size_t)b0 * kDiscOut + q];
                 if (osrc) v = v - off;                               // out[i] - offset (m17_dsp.cpp:217-219)
@@ -154,7 +165,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                     if (b + 1 - b0 >= fe_seen) { duo_wait(&my.fe_rows, b + 2 - b0); fe_seen = lds_peek(&my.fe_rows); }
                 }
                 const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
-                noff = osrc ? osrc[b + 1] : 0.0f;
+                noff = osrc ? duo_offs<PIPE>(&osrc[b + 1]) : 0.0f;
 #pragma unroll
                 for (int r = 0; r < PF; ++r) pf[r] = __builtin_nontemporal_load(&nx[gl + LPC * r]);   // read once
             }
