@@ -278,7 +278,7 @@ def roofline_obj(kms, ncalls, mode, cb_per_launch, key):
     kms = list(kms)
     names = list(KNAMES)
     if 0.0 < kms[0] < 0.05 * kms[1]:
-        # the wave-per-channel FIR stage ran (whole sixteen-block tiles at >= 8,192 channels: k_rx_chan6 = front end, timing loop
+        # the wave-per-channel FIR stage ran (whole sixteen-block tiles at >= 10,000 channels: k_rx_chan6 = front end, timing loop
         # and framer of a channel in one wave): there is no front-end launch, the first interval is the gap between two events
         kms[1] += kms[0]
         kms[0] = 0.0

@@ -244,9 +244,10 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
 // The FIR stage as ONE kernel (m17_fused.hip): front end, timing loop and framer of a channel in one wave, the
 // discriminator samples never leaving the CU.  Not the default: DESIGN.md section 6 (round 4) has the measurements.
 // Which FIR stage runs.  fir_impl 0 (default): the wave-per-channel kernel k_rx_chan6 where it wins -- calls of whole
-// sixteen-block groups (its front-end tiles are sixteen of a channel's own blocks) on batches that give the chip at least
-// two waves per slot (measured at 16,384 channels: -8 % on the full chain at 16 blocks per call, +8 % at 12; nothing
-// at 4,096) -- and front end + timing kernel otherwise.
+// sixteen-block groups (its front-end tiles are sixteen of a channel's own blocks) on batches of at least 10,000 channels
+// (its 6,144 wave slots want well over one generation of waves: full chain at 16 blocks per call against front end +
+// timing kernel: +3 % at 8,192 channels, -2...-5 % at 10,240, -6 % at 12,288, -9 % at 16,384, -7 % at 32,768,
+// profiles/r05_channel_count_crossover.txt) -- and front end + timing kernel otherwise.
 int fir_choice(const m17gpu_ctx *ctx, int nblk);
 // Stream frames as their 192 symbols (slot_impl 1) or regrouped into decoder order by the framer (2)?  Measured at 16,384
 // channels (profiles/r05_plain_frame_slots.txt): the regrouped store costs the framer more than it saves the decoder when
@@ -269,7 +270,7 @@ int fir_choice(const m17gpu_ctx *ctx, int nblk)
     if (ctx->fir_impl == 5) return trio_ok ? 5 : 1;
     if (ctx->fir_impl != 0) return ctx->fir_impl;
     if (trio_ok && nblk >= 16) return 5;
-    return (nblk % 16 == 0 && ctx->C >= 8192) ? 4 : 1;
+    return (nblk % 16 == 0 && ctx->C >= 10000) ? 4 : 1;
 }
 int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
                  int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st)
