@@ -213,20 +213,22 @@ def test_config2_1024_channels_front_end_bit_exact():
     _rx_compare(C=1024, nblk=10, mode=0, ebn0=7.0, nsf=6)
 
 
-@pytest.mark.parametrize("ebn0,options", [(4.0, {}), (8.0, {}), (12.0, {}), (10.0, {"fir_impl": 2}), (10.0, {"fe_impl": 3}), (10.0, {"fir_impl": 3})])
-def test_config4_16384_channels_awgn_bit_exact(ebn0, options):
+@pytest.mark.parametrize("ebn0,options,nblk", [(4.0, {}, 12), (8.0, {}, 12), (12.0, {}, 12), (10.0, {"fir_impl": 2}, 12), (10.0, {"fe_impl": 3}, 12),
+                                               (10.0, {"fir_impl": 3}, 12), (8.0, {}, 16), (200.0, {}, 16), (10.0, {"slot_impl": 2}, 16)])
+def test_config4_16384_channels_awgn_bit_exact(ebn0, options, nblk):
     """BASELINE configs[3] at its real size: 16,384 channels on one GPU, band-limited AWGN, signal from
     the device generator (every channel distinct), DEFAULT options -- so the kernels the bench runs at this size
-     run here at that size -- and, at one Eb/N0 each, the fused FIR-stage kernel and the
-    register-chain front end at that size.  EVERY channel's symbols, symbol counts, records and end state
+     run here at that size: front end + timing kernel at 12 blocks per call, the wave-per-channel
+    stage with plain frame slots at the bench's 16 -- and, at one Eb/N0 each, the fused FIR-stage kernel, the
+    register-chain front end and regrouped slots at that size.  EVERY channel's symbols, symbol counts, records and end state
     are compared with the oracle (m17_rx_sync.cpp:77-99, m17_rx_frame.cpp:126-177 and the decode chain)."""
     torch = _torch()
     import m17_sdr_amd as m
-    C, nblk = 16384, 12
+    C = 16384
     rx = m.Receiver(C, nblk)
     for k, v in options.items():
         rx.set_option(k, v)
-    sig = rx.gen_batch(nblk, n_stream_frames=6, ebn0_db=ebn0, noise_cutoff_hz=6250.0)
+    sig = rx.gen_batch(nblk, n_stream_frames=6, ebn0_db=ebn0, noise_cutoff_hz=6250.0 if ebn0 < 100.0 else 0.0)
     out = rx.rx_blocks(sig["iq"], 1, rx.alloc_outputs(nblk, want_syms=True))
     torch.cuda.synchronize()
     iq = sig["iq"].cpu().numpy()
@@ -351,6 +353,48 @@ def test_config4_state_across_calls_at_full_size():
         np.testing.assert_array_equal(rx.counters(), och.field("counters"))
     delivered = int(((recs["flags"][valid] & m.F_DELIVERED) != 0).sum())
     assert delivered > 10000, delivered                # by the third call LICH assembly is complete on most channels
+    rx.close()
+
+
+@pytest.mark.parametrize("C,lengths", [(37, (16, 3, 32, 1, 20, 16)), (1024, (18, 5, 16)), (10240, (16, 4, 32))])
+def test_calls_of_different_lengths_on_one_context(C, lengths):
+    """The library picks the FIR-stage kernels by call (channel count and blocks per call: DESIGN.md section 5): one
+    context fed one continuous stream in calls of different lengths goes through the three-wave kernel, front end +
+    two-wave / wave kernel and the wave-per-channel kernel in turn, with plain and regrouped frame slots -- every state
+    handed from one kernel family to the other through the channel state.  Every call against the oracle fed the same way."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    total = sum(lengths)
+    rx = m.Receiver(C, max(lengths))
+    gen = m.Receiver(C, total)
+    iq_all = gen.gen_batch(total, n_stream_frames=9, ebn0_db=11.0, noise_cutoff_hz=6250.0)["iq"]
+    gen.close()
+    iq_host = iq_all.cpu().numpy()
+    och = oracle.Channels(C)
+    at = 0
+    parsed = 0
+    for nblk in lengths:
+        part = iq_all[:, at:at + nblk].contiguous()
+        out = rx.rx_blocks(part, 1, rx.alloc_outputs(nblk, want_syms=True))
+        torch.cuda.synchronize()
+        ref = och.rx_blocks(np.ascontiguousarray(iq_host[:, at:at + nblk]), mode=1, nthreads=16, cap=out["rec_cap"])
+        at += nblk
+        counts = out["counts"].cpu().numpy()
+        np.testing.assert_array_equal(counts, ref["counts"])
+        np.testing.assert_array_equal(out["nsyms"].cpu().numpy(), ref["nsyms"])
+        np.testing.assert_array_equal(out["syms"].cpu().numpy().view(np.uint32), ref["syms"].view(np.uint32))
+        recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
+        cap = recs.shape[1]
+        valid = np.arange(cap)[None, :] < counts[:, None]
+        g = recs.view(np.uint8).reshape(C, cap, 64)[valid]
+        r = ref["recs"].view(np.uint8).reshape(C, cap, 64)[valid]
+        bad = np.nonzero((g != r).any(axis=1))[0]
+        assert bad.size == 0, (nblk, bad[:5], g[bad[:1]], r[bad[:1]])
+        np.testing.assert_array_equal(rx.lock(), (och.field("m_flock") != 0).astype(np.uint8))
+        np.testing.assert_array_equal(rx.lsf(), och.field("m_lsf"))
+        np.testing.assert_array_equal(rx.counters(), och.field("counters"))
+        parsed += int(((recs["flags"][valid] & m.F_PARSED) != 0).sum())
+    assert parsed > C * 4, parsed
     rx.close()
 
 
