@@ -321,10 +321,12 @@ void k_rx_chan(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float *
 }
 
 
-// k_rx_chan6 (round 5; option fir_impl 4): k_rx_chan built for SIX waves per SIMD -- frontend_lite_tile (32-sample chunks,
-// ~60 VGPRs, 4.6 KB of LDS) and the timing loop with taps and window through half the registers (sync_wave_channel<1>):
-// the stage is bound by instruction issue at the rate ONE wave can issue (a wave never issues faster than every ~5 cycles,
-// profiles/r03_issue_rates_gfx950.txt), so what a SIMD gets done grows with the waves it holds: 4 -> 6 waves is +15..20 %.
+// k_rx_chan6 (round 5; option fir_impl 4; the library's choice from 10,000 channels on for calls of whole sixteen-block
+// groups): k_rx_chan built for SIX waves per SIMD -- frontend_lite_tile (32-sample chunks, ~60 VGPRs, 4.6 KB of LDS) and the
+// timing loop with taps and window through half the registers (sync_wave_channel<1>).  Measured: the
+// same time as k_rx_chan at four waves per SIMD -- the stage is bound by the vector ALU (~76 % busy) and by its traffic
+// past L2 (4.7-5.1 TB/s), not by what more waves would cover; it is the default of the two for the registers and LDS it
+// leaves.
 constexpr int RC6_LDS = 6144;                  // per wave: the two 2,304-byte tiles / the timing loop's WvChan (4 KB); a multiple of 2 KB (ring alignment)
 static_assert(RC6_LDS >= 2 * FL_TILE_BYTES && RC6_LDS >= (int)sizeof(WvChan) && RC6_LDS % 2048 == 0, "k_rx_chan6 LDS layout");
 __global__ __launch_bounds__(64 * RC_WAVES, 6)

@@ -241,8 +241,6 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
     return M17GPU_OK;
 }
 
-// The FIR stage as ONE kernel (m17_fused.hip): front end, timing loop and framer of a channel in one wave, the
-// discriminator samples never leaving the CU.  Not the default: DESIGN.md section 6 (round 4) has the measurements.
 // Which FIR stage runs.  fir_impl 0 (default): the wave-per-channel kernel k_rx_chan6 where it wins -- calls of whole
 // sixteen-block groups (its front-end tiles are sixteen of a channel's own blocks) on batches of at least 10,000 channels
 // (its 6,144 wave slots want well over one generation of waves: full chain at 16 blocks per call against front end +
