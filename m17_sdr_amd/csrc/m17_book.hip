@@ -248,10 +248,14 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
 __global__ __launch_bounds__(64)
 void k_book_chan(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs, int rec_cap,
                  const int32_t *__restrict__ counts, const uint16_t *__restrict__ crc_basis,
-                 uint8_t *__restrict__ net, const uint16_t *__restrict__ stream_ids, unsigned long long dst_override, int chan0)
+                 uint8_t *__restrict__ net, const uint16_t *__restrict__ stream_ids, unsigned long long dst_override, int chan0,
+                 int32_t *__restrict__ nwork)
 {
     __shared__ LsfShared ls;
     const int lane = lane_id(), chan = (int)blockIdx.x;
+    // the work-list counters of this call have been consumed (the decoder ran in front of this kernel): zero them for the
+    // next call here instead of a fill kernel in front of every call (the context starts with them zeroed)
+    if (nwork && chan == 0 && lane < 4) nwork[lane] = 0;
     ChanState &cs = st[chan];
     m17gpu_rec_dev *crecs = recs + (size_t)chan * rec_cap;
     lsf_shared_init(ls, cs, crc_basis, lane, 64);

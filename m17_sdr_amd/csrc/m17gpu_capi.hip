@@ -327,7 +327,7 @@ int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_c
     HIPCHK(hipGetLastError());
     if (ev_mid) HIPCHK(hipEventRecord(ev_mid, st));
     hipLaunchKernelGGL(k_book_chan, dim3(cn), dim3(64), 0, st, ctx->d_state + c0, recs, rec_cap, cnt, ctx->d_crc_basis,
-                       ctx->d_net, ctx->d_stream_ids, ctx->dst_override, c0);
+                       ctx->d_net, ctx->d_stream_ids, ctx->dst_override, c0, nwork);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -409,6 +409,7 @@ int m17gpu_reset(m17gpu_ctx *ctx, void *stream)
     hipLaunchKernelGGL(k_reset, dim3(cdiv(words, 256)), dim3(256), 0, S(stream), ctx->d_state, ctx->C);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(ctx->d_dec_hist, 0, sizeof(uint32_t) * 32 * (size_t)ctx->C, S(stream)));
+    HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t) * 4, S(stream)));
     return M17GPU_OK;
 }
 
@@ -431,7 +432,7 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
     hipStream_t st = S(stream);
     int rc;
     const bool full = mode == 1;
-    if (full) HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t) * 4, st));
+    // (the work-list counters are zero here: m17gpu_reset zeroed them, and every full-chain call leaves them zeroed -- k_book_chan)
     hipEvent_t *ev = nullptr;
     if (ctx->profiling && ctx->ev_mode.size() < 512) {
         const size_t base = ctx->ev_pool.size();
