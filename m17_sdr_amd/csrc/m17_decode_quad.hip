@@ -256,28 +256,44 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW, NSYM> &F, cons
     // the decision enters the nibble through the carry of dw + dw.  Written out so that every step is exactly these
     // five instructions per state (the compiler's own choice was ~9, with packed adds fed by eight v_mov_dpp).
     // DPP reads need their source two instructions old: every source here was written at least five earlier.
-#define DQ_ACS_(nw, pa, pb, PERM, M, OPA, OPB) do { float tb_;                                            \
-        asm volatile(OPA " %0, %3, %5 quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"                \
-                     OPB " %1, %4, %5 quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"                \
-                     "v_cmp_ngt_f32 vcc, %0, %1\n\t"                                                    \
-                     "v_cndmask_b32 %0, %0, %1, vcc\n\t"                                                \
-                     "v_addc_co_u32 %2, vcc, %2, %2, vcc"                                                \
-                     : "=&v"(nw), "=&v"(tb_), "+v"(dw) : "v"(pa), "v"(pb), "v"(M) : "vcc"); } while (0)
-#define DQ_ACS_P(nw, pa, pb, PERM, M) DQ_ACS_(nw, pa, pb, PERM, M, "v_add_f32_dpp", "v_sub_f32_dpp")    /* metric +M */
-#define DQ_ACS_N(nw, pa, pb, PERM, M) DQ_ACS_(nw, pa, pb, PERM, M, "v_sub_f32_dpp", "v_add_f32_dpp")    /* metric -M */
     // Branch metrics of the lane's four states (round 5): the code is linear, so the expected dibit of state 4j+i (even
     // predecessor) is e(i) xor g(j) -- bm_even = ((j1 ^ i0) << 1) | (j1 ^ j0 ^ i1) -- and with m1' = sg1 m1, m2' = sg2 m2
     // (sg = the lane's signs, those of its state 4j+3) the four metrics are -S, D, -D, S for i = 0..3, S = m1' + m2',
     // D = m1' - m2': one multiply and one packed fma per step instead of two and two, the negations ride on the choice
     // of add / subtract in the butterfly.  Same roundings: sg1 m1 is exact, fma(+-sg2, m2, sg1 m1) rounds the same exact
     // sum the reference's (+-m1) + (+-m2) rounds (m17_conv.cpp:88-91), and -RN(x) = RN(-x).
+    // The step's four add-compare-selects as ONE statement, phase by phase (round 5): all eight DPP adds, then the four
+    // compares -- each into an SGPR pair of its own, not VCC -- then the selects and the carries.  Written one butterfly
+    // after the other (add, sub, compare, select, carry, all through VCC), every instruction waited for the one in front
+    // of it; here four independent chains overlap.  Same instructions, same operands.
 #define DQ_STEP(m1, m2, a0, a1, a2, a3, n0, n1, n2, n3) do {                                              \
         const float t1_ = sg1 * (m1);                                                                   \
         const v2f SD = __builtin_elementwise_fma(K2, (v2f){m2, m2}, (v2f){t1_, t1_});   /* (S, D) */    \
-        DQ_ACS_P(n3, a2, a3, "[1,3,1,3]", SD.x);      /* descending: nibble bit i = decision of state 4j+i */ \
-        DQ_ACS_N(n2, a0, a1, "[1,3,1,3]", SD.y);                                                        \
-        DQ_ACS_P(n1, a2, a3, "[0,2,0,2]", SD.y);                                                        \
-        DQ_ACS_N(n0, a0, a1, "[0,2,0,2]", SD.x); } while (0)
+        float tb3_, tb2_, tb1_, tb0_;                                                                   \
+        unsigned long long k3_, k2_, k1_, k0_;                                                          \
+        asm volatile("v_add_f32_dpp %0, %15, %17 quad_perm:[1,3,1,3] row_mask:0xf bank_mask:0xf\n\t"     /* state 4j+3: +S */ \
+                     "v_sub_f32_dpp %4, %16, %17 quad_perm:[1,3,1,3] row_mask:0xf bank_mask:0xf\n\t"                        \
+                     "v_sub_f32_dpp %1, %13, %18 quad_perm:[1,3,1,3] row_mask:0xf bank_mask:0xf\n\t"     /* state 4j+2: -D */ \
+                     "v_add_f32_dpp %5, %14, %18 quad_perm:[1,3,1,3] row_mask:0xf bank_mask:0xf\n\t"                        \
+                     "v_add_f32_dpp %2, %15, %18 quad_perm:[0,2,0,2] row_mask:0xf bank_mask:0xf\n\t"     /* state 4j+1: +D */ \
+                     "v_sub_f32_dpp %6, %16, %18 quad_perm:[0,2,0,2] row_mask:0xf bank_mask:0xf\n\t"                        \
+                     "v_sub_f32_dpp %3, %13, %17 quad_perm:[0,2,0,2] row_mask:0xf bank_mask:0xf\n\t"     /* state 4j:   -S */ \
+                     "v_add_f32_dpp %7, %14, %17 quad_perm:[0,2,0,2] row_mask:0xf bank_mask:0xf\n\t"                        \
+                     "v_cmp_ngt_f32_e64 %8, %0, %4\n\t"                                                                     \
+                     "v_cmp_ngt_f32_e64 %9, %1, %5\n\t"                                                                     \
+                     "v_cmp_ngt_f32_e64 %10, %2, %6\n\t"                                                                    \
+                     "v_cmp_ngt_f32_e64 %11, %3, %7\n\t"                                                                    \
+                     "v_cndmask_b32_e64 %0, %0, %4, %8\n\t"                                                                 \
+                     "v_addc_co_u32_e64 %12, %8, %12, %12, %8\n\t"      /* descending: nibble bit i = decision of state 4j+i */ \
+                     "v_cndmask_b32_e64 %1, %1, %5, %9\n\t"                                                                 \
+                     "v_addc_co_u32_e64 %12, %9, %12, %12, %9\n\t"                                                          \
+                     "v_cndmask_b32_e64 %2, %2, %6, %10\n\t"                                                                \
+                     "v_addc_co_u32_e64 %12, %10, %12, %12, %10\n\t"                                                        \
+                     "v_cndmask_b32_e64 %3, %3, %7, %11\n\t"                                                                \
+                     "v_addc_co_u32_e64 %12, %11, %12, %12, %11"                                                              \
+                     : "=&v"(n3), "=&v"(n2), "=&v"(n1), "=&v"(n0), "=&v"(tb3_), "=&v"(tb2_), "=&v"(tb1_), "=&v"(tb0_),       \
+                       "=&s"(k3_), "=&s"(k2_), "=&s"(k1_), "=&s"(k0_), "+v"(dw)                                              \
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(SD.x), "v"(SD.y)); } while (0)
     const float sg1 = C1[1].y;
     const v2f K2 = {C2[1].y, -C2[1].y};
     commit_chunk(0);
