@@ -502,6 +502,9 @@ def test_hostile_input_zero_saturated_and_noise():
     _compare_raw(np.ascontiguousarray(iq), mode=1)
     _compare_raw(np.ascontiguousarray(iq), mode=1, options={"sync_impl": 7})
     _compare_raw(np.ascontiguousarray(iq), mode=0, options={"sync_impl": 7})
+    # the front-end tiles of round 5 (halving at the picks, lane moves folded into the DC chain): zeros make NaNs there too
+    for opts in ({"fe_impl": 3}, {"fe_impl": 4}, {"fir_impl": 3}, {"fir_impl": 4}, {"fir_impl": 5}, {"fir_impl": 4, "slot_impl": 2}):
+        _compare_raw(np.ascontiguousarray(iq), mode=1, options=opts)
 
 
 def test_record_capacity_overflow_and_max_blocks():
