@@ -152,6 +152,7 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
             } else if (type == 1) {
                 if (gate_ok) flags |= M17_F_LSF_GATE;
             } else if (type == 2) {
+                flags &= ~(uint32_t)(M17_F_LICH_OK | M17_F_DELIVERED);     // the decoder's guess (m17_decode_quad.hip): decided here
                 g_errors += (w0 >> 16) & 0xFF; n_frames++;
                 // update_lich (m17_rx_parse.cpp:71-85): data[0..5] = words 5 and low half of 6
                 const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)rd0, i), d1 = (uint32_t)__builtin_amdgcn_readlane((int)rd1, i);
