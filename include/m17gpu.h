@@ -162,6 +162,9 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  *   "slot_impl"          how the framer hands a stream frame to the decoder: 1 = its 192 symbols (768 B; the decoder stages
  *                            them in LDS), 2 = regrouped into the order the decoder reads (1,600 B), 0 = by path (default):
  *                            1 behind the wave-per-channel FIR stage, 2 behind front end + timing kernel
+ *   "book_impl"          the bookkeeping kernel: 0 = by batch (default): a lane per channel (k_book_lanes) from 8,192 channels
+ *                            on, a wave per channel (k_book_chan) below and whenever the network sink is attached; 1 / 2 force
+ *                            the wave / the lane kernel (2 still yields to the network sink)
  * and one functional switch:
  *   "afc"                0 (default, as the reference ships: radio.cpp:8) | 1 = radio_set_afc_on(): the
  *                            NCO mixer of m17_dsp.cpp:390-408,468 with the loop of radio.cpp:196-208 per channel.

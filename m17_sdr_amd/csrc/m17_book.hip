@@ -76,6 +76,12 @@ __device__ __forceinline__ uint32_t crc_var_wave(const uint8_t *p, int L, const 
     return xor_reduce64(v) ^ (uint32_t)Z[L];
 }
 
+// ChanState.pad[0]: facts about the channel's LICH / packet buffers that only the bookkeeping kernels change
+constexpr uint32_t BK_VALID = 1u, BK_LSF1_OK = 2u, BK_GATE_OK = 4u, BK_LSF0_GOOD = 8u, BK_EQ01 = 16u;
+//   BK_LSF1_OK  CRC(m_lsf[1]) == 0 (m_lsf[1] only ever changes to CRC-good content)
+//   BK_GATE_OK  CRC(m_packet[0..30)) == 0: decode_link_frame's quirk (m17_rx_parse.cpp:98)
+//   BK_LSF0_GOOD CRC(m_lsf[0]) == 0;  BK_EQ01 m_lsf[1] == m_lsf[0]
+
 struct alignas(16) LsfShared {
     uint16_t basis[240];
     uint8_t  lsf[2][32];
@@ -234,6 +240,13 @@ __device__ void bookkeeping_wave(ChanState &cs, m17gpu_rec_dev *crecs, const m17
     }
     // ---- state back
     if (lane < 30) { ls.lsf[0][lane] = (uint8_t)b0; ls.lsf[1][lane] = (uint8_t)b1; }
+    {
+        // what k_book_lanes would otherwise have to evaluate per channel and call (BK_* bits): both kernels leave it current
+        const bool good0 = crc30_reg(b0, bv, lane) == 0;
+        const bool eq01 = __builtin_amdgcn_ballot_w64(lane < 30 && b0 != b1) == 0ull;
+        if (lane == 0) cs.pad[0] = (int32_t)(BK_VALID | (lsf1_ok ? BK_LSF1_OK : 0u) | (gate_ok ? BK_GATE_OK : 0u) | (good0 ? BK_LSF0_GOOD : 0u) |
+                                             (eq01 ? BK_EQ01 : 0u));
+    }
     if (lane == 0) {
         cs.g_errors = g_errors; cs.n_frames = n_frames; cs.in_frame = in_frame; cs.frame_id_epoch = epoch;
         cs.packet_idx = packet_idx;
@@ -264,6 +277,245 @@ void k_book_chan(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs, 
     bookkeeping_wave(cs, crecs, crecs, min(counts[chan], rec_cap), ls, lane, crc_basis,
                      net ? net + (size_t)(chan0 + chan) * rec_cap * 56 : nullptr,
                      stream_ids ? (uint32_t)stream_ids[chan0 + chan] : 0u, dst_override);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_book_lanes (round 5): the same replay with ONE LANE PER CHANNEL, sixty-four channels per wave.
+//
+// k_book_chan replays a channel's records with uniform control flow -- 790 scalar instructions per channel -- and a CU issues
+// one scalar instruction per cycle for all of its waves: 16,384 channels take 0.041 ms whatever else is done to the kernel
+// (profiles/r05_bookkeeping_kernel_bound.txt).  What the replay does per record is a handful of integer operations,
+// the same for every channel; only the LICH CRC needs lanes side by side, and it needs evaluating only when a chunk
+// CHANGES m_lsf[0] -- once per transmission at most, never in the steady state of a stream.  So: a lane walks its channel's
+// records (loads eight records ahead), keeps the channel's counters in registers and its two LICH buffers in LDS; the lanes
+// whose chunk changed their buffer are served one after the other by the whole wave with the thirty-lane CRC of
+// crc30_reg; what both kernels would otherwise evaluate per call (is m_lsf[1] good, is the packet gate open, ...) sits in
+// the channel state (BK_* bits, kept current by both).  A packet frame (reassembly into the channel's 800-byte buffer,
+// CRCs of variable length; in a stream they only occur as false syncs, a few per thousand channels and call) is served
+// the same way: by the whole wave, for that one record.
+// The network sink is the wave-per-channel kernel's: contexts with one attached launch k_book_chan.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BL_ROW = 80;                      // bytes per lane in LDS: m_lsf[0] at 0, m_lsf[1] at 32 (ChanState layout), 16 spare
+#ifndef BL_CH
+#define BL_CH 8                                 // channels per wave: lanes 0 .. BL_CH - 1 own one each, all 64 serve the CRCs
+#endif
+__global__ __launch_bounds__(64)
+void k_book_lanes(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs, int rec_cap,
+                  const int32_t *__restrict__ counts, const uint16_t *__restrict__ crc_basis,
+                  int32_t *__restrict__ nwork, int cn)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t rows[BL_CH * BL_ROW];
+    __shared__ LsfShared ls;                                            // the wave-per-channel replay of channels with packet frames
+    const int lane = lane_id();
+    const int chan = (int)blockIdx.x * BL_CH + lane;
+    const bool have = lane < BL_CH && chan < cn;
+    if (nwork && blockIdx.x == 0 && lane < 4) nwork[lane] = 0;          // see k_book_chan
+    ChanState &cs = st[have ? chan : cn - 1];
+    m17gpu_rec_dev *crecs = recs + (size_t)(have ? chan : cn - 1) * rec_cap;
+    // the four words the replay needs of every record of the wave's channels (0, 1: type / votes / golay errors / frame
+    // errors, flags / fn; 5, 6: data[0..8), the LICH bytes), staged in LDS by all 64 lanes -- requested in front of everything
+    // else this wave waits for, so that a wave costs one round trip to memory and walks its records out of LDS
+    extern __shared__ __attribute__((aligned(16))) uint32_t recw[];                 // [BL_CH][rec_cap][4]
+    {
+        const int total = BL_CH * rec_cap;
+        for (int base = 0; base < total; base += 4 * 64) {              // four requests per lane in flight, then their LDS writes
+            uint2 a[4]; uint32_t e0[4], e1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 64 + lane;
+                const int ch = min(idx, total - 1) / rec_cap;
+                const int c2 = min((int)blockIdx.x * BL_CH + ch, cn - 1);
+                const uint32_t *r = reinterpret_cast<const uint32_t *>(recs + (size_t)c2 * rec_cap + (min(idx, total - 1) - ch * rec_cap));
+                a[u] = *reinterpret_cast<const uint2 *>(r);
+                e0[u] = r[5]; e1[u] = r[6];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 64 + lane;
+                if (idx < total) *reinterpret_cast<uint4 *>(&recw[4 * idx]) = make_uint4(a[u].x, a[u].y, e0[u], e1[u]);
+            }
+        }
+    }
+    const int n = have ? min(counts[chan], rec_cap) : 0;
+    uint32_t g_errors = cs.g_errors, n_frames = cs.n_frames, in_frame = cs.in_frame, epoch = cs.frame_id_epoch;
+    int packet_idx = cs.packet_idx;
+    uint32_t bk = (uint32_t)cs.pad[0];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(cs.lsf);
+        uint4 *dst = reinterpret_cast<uint4 *>(rows + (lane < BL_CH ? lane : 0) * BL_ROW);
+        const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+        if (lane < BL_CH) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
+    }
+    const uint4 bv = (lane < 30) ? reinterpret_cast<const uint4 *>(crc_basis)[lane] : make_uint4(0u, 0u, 0u, 0u);
+    group_sync();
+    // CRC of thirty bytes at rows[L * BL_ROW + off ..), L wave-uniform: the wave's lanes 0..29 take a byte each
+    auto crc_of = [&](int L, int off) -> bool {
+        const uint32_t b = (lane < 30) ? rows[L * BL_ROW + off + lane] : 0u;
+        return crc30_reg(b, bv, lane) == 0;
+    };
+    // a state that was never left by a bookkeeping kernel (after a reset): evaluate what the BK_* bits say
+    {
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(have && !(bk & BK_VALID));
+        while (todo) {
+            const int L = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const bool ok1 = crc_of(L, 32), good0 = crc_of(L, 0);
+            const uint32_t x = (lane < 30) ? rows[L * BL_ROW + lane] : 0u, y = (lane < 30) ? rows[L * BL_ROW + 32 + lane] : 0u;
+            const bool eq = __builtin_amdgcn_ballot_w64(x != y) == 0ull;
+            // the gate: CRC of the first thirty bytes of the channel's packet buffer
+            const ChanState &cl = st[(int)blockIdx.x * BL_CH + L];
+            const uint32_t pb = (lane < 30) ? cl.packet[lane] : 0u;
+            const bool gate = crc30_reg(pb, bv, lane) == 0;
+            if (lane == L) bk = BK_VALID | (ok1 ? BK_LSF1_OK : 0u) | (gate ? BK_GATE_OK : 0u) | (good0 ? BK_LSF0_GOOD : 0u) | (eq ? BK_EQ01 : 0u);
+        }
+    }
+    bool lsf_dirty = false, pkt_dirty = false;
+    const int maxn = [&]() {                                            // wave maximum of n
+        int m = n;
+        m = max(m, __builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, true));
+        m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x4E, 0xF, 0xF, true));
+        m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x141, 0xF, 0xF, true));
+        m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x140, 0xF, 0xF, true));
+        return max(max(__builtin_amdgcn_readlane(m, 0), __builtin_amdgcn_readlane(m, 16)),
+                   max(__builtin_amdgcn_readlane(m, 32), __builtin_amdgcn_readlane(m, 48)));
+    }();
+    // m_lsf[0] as its six LICH chunks in registers (bytes 5 s .. 5 s + 3 and byte 5 s + 4): what a frame's chunk is compared
+    // with -- in the steady state of a stream it finds itself there, and the iteration touches LDS for its record only
+    uint32_t c32[6], c8[6];
+    {
+        const uint8_t *p = rows + (lane < BL_CH ? lane : 0) * BL_ROW;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            c32[q] = (uint32_t)p[5 * q] | ((uint32_t)p[5 * q + 1] << 8) | ((uint32_t)p[5 * q + 2] << 16) | ((uint32_t)p[5 * q + 3] << 24);
+            c8[q] = p[5 * q + 4];
+        }
+    }
+    const uint32_t *myrec = &recw[4 * ((lane < BL_CH ? lane : 0) * rec_cap)];
+    uint4 rw_next = *reinterpret_cast<const uint4 *>(myrec);
+    for (int i = 0; i < maxn; ++i) {
+        {
+            const uint4 rw = rw_next;
+            rw_next = *reinterpret_cast<const uint4 *>(myrec + 4 * min(i + 1, rec_cap - 1));
+            const uint32_t cw0q = rw.x, cw1q = rw.y, cd0q = rw.z, cd1q = rw.w;
+            const bool act = i < n;
+            const uint32_t w0 = cw0q, w1 = cw1q;
+            uint32_t flags = w1 & 0xFFFFu;
+            const uint32_t type = w0 & 0xFFu;
+            const bool aos = act && (flags & M17_F_AOS);
+            const bool end = act && !aos && (flags & (M17_F_EOT | M17_F_LOST));
+            const bool parsed = act && !aos && !end && (flags & M17_F_PARSED);
+            if (aos) { g_errors = 0; n_frames = 0; in_frame = 1; epoch++; }
+            if (end) { in_frame = 0; epoch++; }
+            const uint32_t old_flags = flags;
+            if (parsed && (type == 0 || type == 5)) epoch++;
+            if (parsed && type == 1 && (bk & BK_GATE_OK)) flags |= M17_F_LSF_GATE;
+            const bool strm = parsed && type == 2;
+            bool need_crc = false;
+            bool chunk = false;
+            if (strm) {
+                flags &= ~(uint32_t)(M17_F_LICH_OK | M17_F_DELIVERED);     // the decoder's guess: decided here
+                g_errors += (w0 >> 16) & 0xFFu; n_frames++;
+                // update_lich (m17_rx_parse.cpp:71-85): data[0..5], counter in data[5] >> 5
+                const uint32_t d0 = cd0q, d1 = cd1q;
+                const uint32_t seq = ((d1 >> 8) & 0xFFu) >> 5;
+                if (seq < 6) {
+                    chunk = true;
+                    uint32_t o32 = c32[0], o8 = c8[0];
+#pragma unroll
+                    for (int q = 1; q < 6; ++q) { o32 = (seq == (uint32_t)q) ? c32[q] : o32; o8 = (seq == (uint32_t)q) ? c8[q] : o8; }
+                    need_crc = o32 != d0 || o8 != (d1 & 0xFFu);
+                }
+            }
+            // the lanes whose chunk changed m_lsf[0]: registers and LDS row updated, then its CRC, by the whole wave, one lane after the other
+            {
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(need_crc);
+                if (todo) {
+                    if (need_crc) {
+                        const uint32_t d0 = cd0q, d1 = cd1q;
+                        const uint32_t seq = ((d1 >> 8) & 0xFFu) >> 5;
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) { if (seq == (uint32_t)q) { c32[q] = d0; c8[q] = d1 & 0xFFu; } }
+                        uint8_t *p = rows + (lane < BL_CH ? lane : 0) * BL_ROW + seq * 5;
+                        p[0] = (uint8_t)d0; p[1] = (uint8_t)(d0 >> 8); p[2] = (uint8_t)(d0 >> 16); p[3] = (uint8_t)(d0 >> 24); p[4] = (uint8_t)d1;
+                        lsf_dirty = true;
+                        bk &= ~BK_EQ01;
+                    }
+                    wave_fence();
+                    while (todo) {
+                        const int L = (int)__builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        const bool good0 = crc_of(L, 0);
+                        if (lane == L) bk = (bk & ~BK_LSF0_GOOD) | (good0 ? BK_LSF0_GOOD : 0u);
+                    }
+                }
+            }
+            // packet frames (parse_packet, m17_rx_parse.cpp:34-51): the wave serves them one after the other
+            {
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(parsed && type == 3);
+                while (todo) {
+                    const int L = (int)__builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const int c2 = (int)blockIdx.x * BL_CH + L;
+                    ChanState &c2s = st[c2];
+                    const m17gpu_rec_dev *r2 = recs + (size_t)c2 * rec_cap + i;
+                    int pidx = __builtin_amdgcn_readlane(packet_idx, L);
+                    const uint8_t *dbytes = reinterpret_cast<const uint8_t *>(reinterpret_cast<const uint32_t *>(r2) + 5);
+                    const uint32_t d25 = (uint32_t)uni((int)dbytes[25]);                          // data[25]
+                    const int eof = (int)(d25 >> 7), fnv = (int)((d25 >> 2) & 0x1F);
+                    bool valid_pkt = false;
+                    if (eof) {
+                        int cnt = fnv;
+                        if (pidx + cnt > 800) cnt = 800 - pidx;
+                        if (lane < cnt) c2s.packet[pidx + lane] = dbytes[lane];
+                        pidx += cnt;
+                        group_sync();
+                        for (int q = lane; q < 200; q += 64) reinterpret_cast<uint32_t *>(ls.packet)[q] = reinterpret_cast<const uint32_t *>(c2s.packet)[q];
+                        group_sync();
+                        valid_pkt = crc_var_wave(ls.packet, pidx, crc_basis, lane) == 0;
+                        pidx = 0;
+                    } else {
+                        if (lane < 25) c2s.packet[fnv * 25 + lane] = dbytes[lane];
+                        pidx = fnv * 25;
+                        group_sync();
+                    }
+                    const uint32_t pb = (lane < 30) ? c2s.packet[lane] : 0u;
+                    const bool gate = crc30_reg(pb, bv, lane) == 0;
+                    if (lane == L) {
+                        packet_idx = pidx;
+                        if (valid_pkt) flags |= M17_F_PKT_VALID;
+                        bk = (bk & ~BK_GATE_OK) | (gate ? BK_GATE_OK : 0u);
+                        pkt_dirty = true;
+                    }
+                }
+            }
+            if (chunk && (bk & BK_LSF0_GOOD)) {
+                if (!(bk & BK_EQ01)) {                                      // copy_lich: m_lsf[1] = m_lsf[0]
+                    const uint4 *s4 = reinterpret_cast<const uint4 *>(rows + (lane < BL_CH ? lane : 0) * BL_ROW);
+                    uint4 *d4 = reinterpret_cast<uint4 *>(rows + (lane < BL_CH ? lane : 0) * BL_ROW + 32);
+                    const uint4 a = s4[0], b = s4[1];
+                    d4[0] = a; d4[1] = b;
+                    bk |= BK_EQ01; lsf_dirty = true;
+                }
+                bk |= BK_LSF1_OK;
+                flags |= M17_F_LICH_OK;
+            }
+            if (strm && (bk & BK_LSF1_OK)) flags |= M17_F_DELIVERED;        // :148
+            if (parsed && flags != old_flags)
+                reinterpret_cast<uint32_t *>(&crecs[i])[1] = (w1 & 0xFFFF0000u) | flags;
+        }
+    }
+    // ---- state back
+    wave_fence();
+    if (have) {
+        cs.g_errors = g_errors; cs.n_frames = n_frames; cs.in_frame = in_frame; cs.frame_id_epoch = epoch;
+        cs.pad[0] = (int32_t)bk;
+        if (pkt_dirty) cs.packet_idx = packet_idx;
+        if (lsf_dirty) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(rows + (lane < BL_CH ? lane : 0) * BL_ROW);
+            uint4 *dst = reinterpret_cast<uint4 *>(cs.lsf);
+            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+        }
+    }
 }
 
 // LSF field extraction for n LSFs (parse_lsf m17_rx_parse.cpp:52-70 with m17_decode_call m17_bit_utils.cpp:209-226 and

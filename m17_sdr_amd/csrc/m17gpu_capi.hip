@@ -56,6 +56,8 @@ struct m17gpu_ctx {
     int sync_impl = 0;                       // 0 | 6 = timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond (default);
                                              // 7 = wave per channel at every size
     int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
+    int book_impl = 0;                       // bookkeeping kernel: 0 = by batch (a lane per channel from 8,192 channels on, else a wave per channel), 1 = a wave
+                                             // per channel (k_book_chan; always with the network sink attached), 2 = a lane per channel (k_book_lanes)
     int slot_impl = 0;                       // stream frame slots: 1 = plain (768 B, regrouped in the decoder's LDS), 2 = regrouped by the framer (1,600 B),
                                              // 0 = by path: plain behind the wave-per-channel FIR stage, regrouped behind front end + timing kernel
     int32_t *d_flags = nullptr;              // [n_flags] verdict words of m17gpu_shard_gather_packed
@@ -326,6 +328,12 @@ int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_c
                        ctx->d_genc, ctx->d_gerr, kSlotFloats, n_other);
     HIPCHK(hipGetLastError());
     if (ev_mid) HIPCHK(hipEventRecord(ev_mid, st));
+    // bookkeeping: a lane per channel (k_book_lanes) for large batches -- it is ~25 us whatever the batch, the wave-per-channel
+    // kernel 19 us at 4,096 channels x 16 blocks, 28 at 8,192, 42 at 16,384, 80 at 32,768 -- unless the network sink is attached
+    // (its frames are formatted by the wave-per-channel kernel); book_impl 1 / 2 force one
+    if (!ctx->d_net && (ctx->book_impl == 2 || (ctx->book_impl == 0 && cn >= 8192)))
+        hipLaunchKernelGGL(k_book_lanes, dim3(cdiv(cn, BL_CH)), dim3(64), (size_t)BL_CH * rec_cap * 16, st, ctx->d_state + c0, recs, rec_cap, cnt, ctx->d_crc_basis, nwork, cn);
+    else
     hipLaunchKernelGGL(k_book_chan, dim3(cn), dim3(64), 0, st, ctx->d_state + c0, recs, rec_cap, cnt, ctx->d_crc_basis,
                        ctx->d_net, ctx->d_stream_ids, ctx->dst_override, c0, nwork);
     HIPCHK(hipGetLastError());
@@ -586,6 +594,7 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "fir_impl")) { if (value < 0 || value > 5) return bad(); ctx->fir_impl = value; }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
     else if (!std::strcmp(name, "slot_impl")) { if (value < 0 || value > 2) return bad(); ctx->slot_impl = value; }
+    else if (!std::strcmp(name, "book_impl")) { if (value < 0 || value > 2) return bad(); ctx->book_impl = value; }
 
 #ifdef M17_STAMPS
     else if (!std::strcmp(name, "fe_debug")) { ctx->fe_debug = value; }      // instrumented build only: WRONG results

@@ -69,6 +69,34 @@ def test_streaming_state_across_calls():
     _rx_compare(C=33, nblk=5, mode=1, ebn0=200.0, calls=5)
 
 
+@pytest.mark.parametrize("packet_mode", [0, 1])
+def test_bookkeeping_kernels_hand_state_to_each_other(packet_mode):
+    """k_book_chan (a wave per channel) and k_book_lanes (a lane per channel) keep the same per-channel facts in the channel
+    state (is m_lsf[1] good, is the packet gate open, ...): one context, the kernel changing from call to call, every call
+    against the oracle fed the same way -- records with their flags, LICH buffers and counters."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    C, nblk, calls = 70, 6, 8
+    sig = m.generate_batch(C, nblk * calls, n_stream_frames=7, ebn0_db=13.0, packet_mode=packet_mode, base_seed=0x4D313755)
+    rx = m.Receiver(C, nblk)
+    och = oracle.Channels(C)
+    for k in range(calls):
+        rx.set_option("book_impl", 1 + ((k + (k >> 2)) & 1))
+        part = np.ascontiguousarray(sig["iq"][:, k * nblk:(k + 1) * nblk])
+        out = rx.rx_blocks(torch.from_numpy(part).cuda(), 1, rx.alloc_outputs(nblk))
+        torch.cuda.synchronize()
+        ref = och.rx_blocks(part, mode=1, want_syms=False)
+        counts = out["counts"].cpu().numpy()
+        np.testing.assert_array_equal(counts, ref["counts"])
+        recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
+        for c in range(C):
+            n = min(counts[c], recs.shape[1])
+            assert recs[c, :n].tobytes() == ref["recs"][c, :n].tobytes(), (k, c, recs[c, :n], ref["recs"][c, :n])
+        np.testing.assert_array_equal(rx.lsf(), och.field("m_lsf"))
+        np.testing.assert_array_equal(rx.counters(), och.field("counters"))
+    rx.close()
+
+
 def test_packet_mode():
     _rx_compare(C=40, nblk=16, mode=1, ebn0=200.0, packet_mode=1)
 
@@ -162,7 +190,7 @@ def test_exact_arithmetic_selftest():
 
 
 @pytest.mark.parametrize("options", [
-    {"sync_impl": 6}, {"sync_impl": 7}, {"sync_impl": 8}, {"sync_impl": 9}, {"fe_impl": 1}, {"fe_impl": 2}, {"fe_impl": 3}, {"fe_impl": 4}, {"fir_impl": 1}, {"fir_impl": 2}, {"fir_impl": 3}, {"fir_impl": 4}, {"fir_impl": 5}, {"fir_impl": 5, "sync_impl": 6}, {"fir_impl": 1, "sync_impl": 7}, {"slot_impl": 1}, {"slot_impl": 2}, {"slot_impl": 1, "fir_impl": 4}, {"slot_impl": 2, "fir_impl": 4}])
+    {"sync_impl": 6}, {"sync_impl": 7}, {"sync_impl": 8}, {"sync_impl": 9}, {"fe_impl": 1}, {"fe_impl": 2}, {"fe_impl": 3}, {"fe_impl": 4}, {"fir_impl": 1}, {"fir_impl": 2}, {"fir_impl": 3}, {"fir_impl": 4}, {"fir_impl": 5}, {"fir_impl": 5, "sync_impl": 6}, {"fir_impl": 1, "sync_impl": 7}, {"slot_impl": 1}, {"slot_impl": 2}, {"book_impl": 1}, {"book_impl": 2}, {"book_impl": 2, "fir_impl": 4}, {"slot_impl": 1, "fir_impl": 4}, {"slot_impl": 2, "fir_impl": 4}])
 def test_every_kernel_variant_is_bit_exact(options):
     _rx_compare(C=40, nblk=22, mode=1, ebn0=200.0, nsf=12, options=options)
     _rx_compare(C=40, nblk=9, mode=1, ebn0=9.0, nsf=5, calls=3, options=options)
@@ -548,11 +576,11 @@ def test_set_option_rejects_unknown_and_out_of_range_values():
     import m17_sdr_amd as m
     rx = m.Receiver(2, 2)
     for name, value in (("fe_impl", 101), ("fe_impl", 107), ("fe_impl", -1), ("fe_impl", 5), ("sync_impl", 2),
-                        ("sync_impl", 5), ("sync_impl", 1), ("sync_impl", 4), ("sync_impl", 10), ("fir_impl", 6), ("fir_impl", -1), ("slot_impl", 3), ("overlap_chunks", 2), ("fe_waves_per_cu", 8), ("lanes_per_channel", 16),
+                        ("sync_impl", 5), ("sync_impl", 1), ("sync_impl", 4), ("sync_impl", 10), ("fir_impl", 6), ("fir_impl", -1), ("slot_impl", 3), ("book_impl", 3), ("overlap_chunks", 2), ("fe_waves_per_cu", 8), ("lanes_per_channel", 16),
                         ("decode_impl", 0), ("no_such_option", 1)):
         with pytest.raises(RuntimeError):
             rx.set_option(name, value)
-    for name, value in (("fe_impl", 0), ("fe_impl", 1), ("fe_impl", 2), ("fe_impl", 3), ("fe_impl", 4), ("sync_impl", 0), ("sync_impl", 6), ("sync_impl", 7), ("sync_impl", 8), ("sync_impl", 9), ("fir_impl", 0), ("fir_impl", 1), ("fir_impl", 2), ("fir_impl", 3), ("fir_impl", 4), ("fir_impl", 5), ("slot_impl", 1), ("slot_impl", 2), ("slot_impl", 0)):
+    for name, value in (("fe_impl", 0), ("fe_impl", 1), ("fe_impl", 2), ("fe_impl", 3), ("fe_impl", 4), ("sync_impl", 0), ("sync_impl", 6), ("sync_impl", 7), ("sync_impl", 8), ("sync_impl", 9), ("fir_impl", 0), ("fir_impl", 1), ("fir_impl", 2), ("fir_impl", 3), ("fir_impl", 4), ("fir_impl", 5), ("slot_impl", 1), ("slot_impl", 2), ("slot_impl", 0), ("book_impl", 1), ("book_impl", 2), ("book_impl", 0)):
         rx.set_option(name, value)
     rx.close()
 
