@@ -316,37 +316,45 @@ void k_book_lanes(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs,
     // errors, flags / fn; 5, 6: data[0..8), the LICH bytes), staged in LDS by all 64 lanes -- requested in front of everything
     // else this wave waits for, so that a wave costs one round trip to memory and walks its records out of LDS
     extern __shared__ __attribute__((aligned(16))) uint32_t recw[];                 // [BL_CH][rec_cap][4]
-    {
-        const int total = BL_CH * rec_cap;
-        for (int base = 0; base < total; base += 4 * 64) {              // four requests per lane in flight, then their LDS writes
-            uint2 a[4]; uint32_t e0[4], e1[4];
+    // every load of the prologue is requested before the first wait: the count, the state's scalars, the two LICH buffers,
+    // the CRC basis, and the first eight records' words per lane (512 of the wave's BL_CH x rec_cap records; the rest, for
+    // calls of more than 31 blocks, in further rounds of eight)
+    const int total = BL_CH * rec_cap;
+    constexpr int BL_G = 8;
+    uint2 sa[BL_G]; uint32_t se0[BL_G], se1[BL_G];
+    auto stage_request = [&](int base) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * 64 + lane;
-                const int ch = min(idx, total - 1) / rec_cap;
-                const int c2 = min((int)blockIdx.x * BL_CH + ch, cn - 1);
-                const uint32_t *r = reinterpret_cast<const uint32_t *>(recs + (size_t)c2 * rec_cap + (min(idx, total - 1) - ch * rec_cap));
-                a[u] = *reinterpret_cast<const uint2 *>(r);
-                e0[u] = r[5]; e1[u] = r[6];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * 64 + lane;
-                if (idx < total) *reinterpret_cast<uint4 *>(&recw[4 * idx]) = make_uint4(a[u].x, a[u].y, e0[u], e1[u]);
-            }
+        for (int u = 0; u < BL_G; ++u) {
+            const int idx = min(base + u * 64 + lane, total - 1);
+            const int ch = idx / rec_cap;
+            const int c2 = min((int)blockIdx.x * BL_CH + ch, cn - 1);
+            const uint32_t *r = reinterpret_cast<const uint32_t *>(recs + (size_t)c2 * rec_cap + (idx - ch * rec_cap));
+            sa[u] = *reinterpret_cast<const uint2 *>(r);
+            se0[u] = r[5]; se1[u] = r[6];
         }
-    }
-    const int n = have ? min(counts[chan], rec_cap) : 0;
+    };
+    auto stage_commit = [&](int base) {
+#pragma unroll
+        for (int u = 0; u < BL_G; ++u) {
+            const int idx = base + u * 64 + lane;
+            if (idx < total) *reinterpret_cast<uint4 *>(&recw[4 * idx]) = make_uint4(sa[u].x, sa[u].y, se0[u], se1[u]);
+        }
+    };
+    const int cnt_raw = have ? counts[chan] : 0;
     uint32_t g_errors = cs.g_errors, n_frames = cs.n_frames, in_frame = cs.in_frame, epoch = cs.frame_id_epoch;
     int packet_idx = cs.packet_idx;
     uint32_t bk = (uint32_t)cs.pad[0];
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(cs.lsf);
-        uint4 *dst = reinterpret_cast<uint4 *>(rows + (lane < BL_CH ? lane : 0) * BL_ROW);
-        const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
-        if (lane < BL_CH) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
-    }
+    const uint4 *lsrc = reinterpret_cast<const uint4 *>(cs.lsf);
+    const uint4 la = lsrc[0], lb = lsrc[1], lc = lsrc[2], ld = lsrc[3];
     const uint4 bv = (lane < 30) ? reinterpret_cast<const uint4 *>(crc_basis)[lane] : make_uint4(0u, 0u, 0u, 0u);
+    stage_request(0);
+    const int n = have ? min(cnt_raw, rec_cap) : 0;
+    if (lane < BL_CH) {
+        uint4 *dst = reinterpret_cast<uint4 *>(rows + lane * BL_ROW);
+        dst[0] = la; dst[1] = lb; dst[2] = lc; dst[3] = ld;
+    }
+    stage_commit(0);
+    for (int base = BL_G * 64; base < total; base += BL_G * 64) { stage_request(base); stage_commit(base); }
     group_sync();
     // CRC of thirty bytes at rows[L * BL_ROW + off ..), L wave-uniform: the wave's lanes 0..29 take a byte each
     auto crc_of = [&](int L, int off) -> bool {
