@@ -331,7 +331,8 @@ int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_c
     // bookkeeping: a lane per channel (k_book_lanes) for large batches -- it is ~25 us whatever the batch, the wave-per-channel
     // kernel 19 us at 4,096 channels x 16 blocks, 28 at 8,192, 42 at 16,384, 80 at 32,768 -- unless the network sink is attached
     // (its frames are formatted by the wave-per-channel kernel); book_impl 1 / 2 force one
-    if (!ctx->d_net && (ctx->book_impl == 2 || (ctx->book_impl == 0 && cn >= 8192)))
+    // (its LDS holds four words of every record of its eight channels: calls of more than ~190 blocks stay with the wave kernel)
+    if (!ctx->d_net && (size_t)BL_CH * rec_cap * 16 <= 48 * 1024 && (ctx->book_impl == 2 || (ctx->book_impl == 0 && cn >= 8192)))
         hipLaunchKernelGGL(k_book_lanes, dim3(cdiv(cn, BL_CH)), dim3(64), (size_t)BL_CH * rec_cap * 16, st, ctx->d_state + c0, recs, rec_cap, cnt, ctx->d_crc_basis, nwork, cn);
     else
     hipLaunchKernelGGL(k_book_chan, dim3(cn), dim3(64), 0, st, ctx->d_state + c0, recs, rec_cap, cnt, ctx->d_crc_basis,

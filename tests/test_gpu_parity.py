@@ -97,6 +97,13 @@ def test_bookkeeping_kernels_hand_state_to_each_other(packet_mode):
     rx.close()
 
 
+@pytest.mark.parametrize("nblk", [150, 200])
+def test_lane_bookkeeping_on_very_long_calls(nblk):
+    """k_book_lanes keeps four words of every record of its eight channels in LDS: 38 KB at 150 blocks per call; at 200 it
+    would be 51 KB and the library stays with the wave-per-channel kernel even when the lane kernel is asked for."""
+    _rx_compare(C=11, nblk=nblk, mode=1, ebn0=12.0, nsf=20, options={"book_impl": 2})
+
+
 def test_packet_mode():
     _rx_compare(C=40, nblk=16, mode=1, ebn0=200.0, packet_mode=1)
 
