@@ -280,14 +280,15 @@ void k_book_chan(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_book_lanes (round 5): the same replay with ONE LANE PER CHANNEL, sixty-four channels per wave.
+// k_book_lanes (round 5): the same replay with ONE LANE PER CHANNEL (BL_CH = 8 channel lanes per wave; all 64 lanes serve).
 //
 // k_book_chan replays a channel's records with uniform control flow -- 790 scalar instructions per channel -- and a CU issues
 // one scalar instruction per cycle for all of its waves: 16,384 channels take 0.041 ms whatever else is done to the kernel
 // (profiles/r05_bookkeeping_kernel_bound.txt).  What the replay does per record is a handful of integer operations,
 // the same for every channel; only the LICH CRC needs lanes side by side, and it needs evaluating only when a chunk
 // CHANGES m_lsf[0] -- once per transmission at most, never in the steady state of a stream.  So: a lane walks its channel's
-// records (loads eight records ahead), keeps the channel's counters in registers and its two LICH buffers in LDS; the lanes
+// records (their words staged in LDS by the whole wave), keeps the channel's counters and the six LICH chunks of m_lsf[0] in
+// registers and the two LICH buffers in LDS; the lanes
 // whose chunk changed their buffer are served one after the other by the whole wave with the thirty-lane CRC of
 // crc30_reg; what both kernels would otherwise evaluate per call (is m_lsf[1] good, is the packet gate open, ...) sits in
 // the channel state (BK_* bits, kept current by both).  A packet frame (reassembly into the channel's 800-byte buffer,
@@ -305,7 +306,7 @@ void k_book_lanes(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs,
                   int32_t *__restrict__ nwork, int cn)
 {
     __shared__ __attribute__((aligned(16))) uint8_t rows[BL_CH * BL_ROW];
-    __shared__ LsfShared ls;                                            // the wave-per-channel replay of channels with packet frames
+    __shared__ LsfShared ls;                                            // its packet buffer: the variable-length CRC of a packet frame
     const int lane = lane_id();
     const int chan = (int)blockIdx.x * BL_CH + lane;
     const bool have = lane < BL_CH && chan < cn;
@@ -313,8 +314,7 @@ void k_book_lanes(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs,
     ChanState &cs = st[have ? chan : cn - 1];
     m17gpu_rec_dev *crecs = recs + (size_t)(have ? chan : cn - 1) * rec_cap;
     // the four words the replay needs of every record of the wave's channels (0, 1: type / votes / golay errors / frame
-    // errors, flags / fn; 5, 6: data[0..8), the LICH bytes), staged in LDS by all 64 lanes -- requested in front of everything
-    // else this wave waits for, so that a wave costs one round trip to memory and walks its records out of LDS
+    // errors, flags / fn; 5, 6: data[0..8), the LICH bytes), staged in LDS by all 64 lanes
     extern __shared__ __attribute__((aligned(16))) uint32_t recw[];                 // [BL_CH][rec_cap][4]
     // every load of the prologue is requested before the first wait: the count, the state's scalars, the two LICH buffers,
     // the CRC basis, and the first eight records' words per lane (512 of the wave's BL_CH x rec_cap records; the rest, for
