@@ -149,8 +149,8 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  *   "fe_impl"            0 = by size (default), 1 = lane per channel-block, 2 = four lanes per
  *                            channel-block, 3 = four lanes with the DC chain and the /5 pick in registers,
  *                            4 = the same on 32-sample chunks (76 VGPRs, 4.6 KB of LDS: the tile of k_rx_chan6)
- *   "fir_impl"           0 = by call (default): 5 up to 1,024 channels for calls of >= 16 blocks, 4 for calls of whole
- *                            sixteen-block groups on >= 10,000 channels, else 1;
+ *   "fir_impl"           0 = by call (default): 5 up to 1,024 channels (calls of >= 16 blocks: from 512 channels on),
+ *                            4 for calls of whole sixteen-block groups on >= 10,000 channels, else 1;
  *                            1 = front end and timing / framer as two kernels; 2 = the whole FIR stage of a
  *                            channel in one wave, four blocks at a time through LDS (k_rx_fused: no discriminator rows
  *                            in HBM; measured slower); 3 = a wave per channel that runs the front
@@ -158,7 +158,8 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  *                            rows through the workspace (k_rx_chan); 4 = that built for six waves per SIMD (k_rx_chan6);
  *                            5 = up to 1,024 channels: front end, timing loop and framer of a channel on three waves of
  *                            one workgroup, the front end sixteen blocks ahead of the timing loop (k_sync_frame_duo<1>;
- *                            falls back to 1 where the two-wave timing kernel does not apply)
+ *                            calls of up to eight blocks start on four-row tiles; falls back to 1 where the two-wave
+ *                            timing kernel does not apply)
  *   "slot_impl"          how the framer hands a stream frame to the decoder: 1 = its 192 symbols (768 B; the decoder stages
  *                            them in LDS), 2 = regrouped into the order the decoder reads (1,600 B), 0 = by path (default):
  *                            1 behind the wave-per-channel FIR stage, 2 behind front end + timing kernel

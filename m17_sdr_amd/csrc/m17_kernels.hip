@@ -695,6 +695,128 @@ __device__ __forceinline__ void frontend_tile(const uint4 *__restrict__ iq, Chan
         }
     }
 }
+template <int CTRL> __device__ __forceinline__ float dpp_keep(float old, float src)    // lanes without a source keep `old`
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xF, 0xF, false));
+}
+// value of lane l-1 of the row; lane 0: lane 15's value of `prev` (the row's previous chunk)
+__device__ __forceinline__ float fu_left(float cur, float prev)
+{
+    const float t = dpp_keep<0x121>(prev, prev);          // row_ror:1
+    return dpp_keep<0x111>(t, cur);                       // row_shr:1
+}
+
+// The DC sum of one chunk (m17_dsp.cpp:211: offset += out, strictly in sample order): on entry `carry` holds, in lane
+// 0 of each row, the row's sum so far; u0..u3 the lane's four values, a0..a3 the same with exact zeros in lane 0.
+// Lane 0 finishes in the first four adds; after step j lanes 0..j hold their final sums (lane l <= j recomputes the
+// same value from lane l-1's final one; lane 0 is disabled for the DPP add -- no source, bound_ctrl 0 -- and adds
+// zeros, which is exact: a running sum that starts at +0 never is -0).  Leaves the row's new sum in lane 0 of `carry`.
+// (s_nop 1: a VALU write followed by a DPP read of the same register needs two wait states on gfx9.)
+#define FU_STEP "s_nop 1\n\tv_add_f32_dpp %0, %0, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+                "v_add_f32 %0, %0, %7\n\tv_add_f32 %0, %0, %8\n\tv_add_f32 %0, %0, %9\n\t"
+__device__ __forceinline__ void fu_chain(float &carry, float u0, float u1, float u2, float u3, float a0, float a1, float a2, float a3)
+{
+    float T;
+    asm volatile("v_add_f32 %0, %1, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %0, %0, %4\n\tv_add_f32 %0, %0, %5\n\t"
+                 FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP
+                 "s_nop 1\n\tv_mov_b32_dpp %1, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(T), "+v"(carry) : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+}
+
+
+// A QUICK tile: FOUR rows of sixteen lanes (k_rx_fused's front-end phase, m17_fused.hip, as a device function that
+// stores to the workspace like frontend_tile).  A lone wave needs ~40 % of a sixteen-row tile's time for it -- each lane
+// converts 120 samples instead of 480, the 1,920-step DC chain costs the same -- so it is what the three waves of a
+// channel in k_sync_frame_duo<1> run first, side by side, to get the timing loop started (round 5).
+//   load    : lane (r, l) of chunk c reads the uint4 with samples 64c + 4l .. + 3 of row r; two register sets of five chunks
+//   compute : the lane's own four samples; the two before them by DPP row_shr:1 (lane 0: the row's previous chunk)
+//   DC sum  : fu_chain; /5 pick: sample s is an output iff s % 5 == 4 -- with q = (c + l) % 5 the lane's pick is its
+//             sample q - 1 (none for q == 0), stored straight to its place in the row
+// rowmap(i, valid), i = 0 .. 3: as for frontend_tile.
+template <class RowMap>
+__device__ __forceinline__ void frontend_quick4(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
+                                                float *__restrict__ disc_raw, float *__restrict__ offs,
+                                                int nblk, int update_state, RowMap rowmap, const int lane)
+{
+    constexpr int P = 5, NCHUNK = kBlockSamples / 64;
+    static_assert(NCHUNK % (2 * P) == 0, "quick tile passes");
+    const int r = lane >> 4, l = lane & 15;
+    bool valid;
+    const int cb = rowmap(r, valid);
+    const int chan = cb / nblk, blk = cb - chan * nblk;
+    float p3re, p3im, p2re, p2im;                          // sample -1 (z0) and -2 (z1) of the row, in every lane
+    float n0re = 0.0f, n0im = 0.0f, n1re = 0.0f, n1im = 0.0f;
+    if (blk == 0) {
+        p3re = st[chan].z0re; p3im = st[chan].z0im; p2re = st[chan].z1re; p2im = st[chan].z1im;
+        fe_next_z(iq, cb, nblk, n0re, n0im, n1re, n1im);
+    } else {
+        const uint32_t *pw = reinterpret_cast<const uint32_t *>(iq) + (size_t)cb * kBlockSamples;
+        const uint32_t a = pw[-2], b = pw[-1];
+        p2re = s16_to_float((int)(short)(a & 0xFFFF)); p2im = s16_to_float((int)a >> 16);
+        p3re = s16_to_float((int)(short)(b & 0xFFFF)); p3im = s16_to_float((int)b >> 16);
+        limit(p2re, p2im);
+        limit(p3re, p3im);
+    }
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    const uint4 *const rowp = iq + (size_t)cb * (kBlockSamples / 4) + l;
+    auto load_chunk = [&](int c) { return __builtin_nontemporal_load(reinterpret_cast<const u4v *>(rowp + c * 16)); };
+    float *const dst = disc_raw + (size_t)cb * kDiscOut;
+    float carry = 0.0f;                                    // offset = 0 (m17_dsp.cpp:199)
+    int q = l % 5;                                         // (c + l) % 5
+    const bool first = l == 0;
+    auto chunk = [&](const u4v v, const int c) {
+        const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+        float re[4], im[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            re[k] = s16_to_float((int)(short)(ww[k] & 0xFFFF));
+            im[k] = s16_to_float((int)ww[k] >> 16);
+            limit(re[k], im[k]);
+        }
+        const float m1re = fu_left(re[3], p3re), m1im = fu_left(im[3], p3im);     // sample -1 of this lane's run
+        const float m2re = fu_left(re[2], p2re), m2im = fu_left(im[2], p2im);     // sample -2
+        p3re = re[3]; p3im = im[3]; p2re = re[2]; p2im = im[2];
+        float u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // dsp_arctan_disc2 (m17_dsp.cpp:194-222): z0 = sample k-1, z1 = sample k-2
+            const float z0re = k >= 1 ? re[k >= 1 ? k - 1 : 0] : m1re, z0im = k >= 1 ? im[k >= 1 ? k - 1 : 0] : m1im;
+            const float z1re = k >= 2 ? re[k >= 2 ? k - 2 : 0] : (k == 1 ? m1re : m2re);
+            const float z1im = k >= 2 ? im[k >= 2 ? k - 2 : 0] : (k == 1 ? m1im : m2im);
+            const float aa = z0im * (re[k] - z1re);
+            const float bb = z0re * (im[k] - z1im);
+            u[k] = (bb - aa) * 0.5f;
+        }
+        fu_chain(carry, u[0], u[1], u[2], u[3], first ? 0.0f : u[0], first ? 0.0f : u[1], first ? 0.0f : u[2], first ? 0.0f : u[3]);
+        const float pick = q == 1 ? u[0] : (q == 2 ? u[1] : (q == 3 ? u[2] : u[3]));
+        const unsigned oidx = ((unsigned)(64 * c + 4 * l + q - 5) * 52429u) >> 18;        // (s - 4) / 5, s = 64c + 4l + q - 1
+        if (q != 0 && valid) dst[oidx] = pick;
+        q = (q == 4) ? 0 : q + 1;
+    };
+    u4v wa[P], wb[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) wa[j] = load_chunk(j);
+    for (int c0 = 0; c0 < NCHUNK; c0 += 2 * P) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) wb[j] = load_chunk(c0 + P + j);
+#pragma unroll
+        for (int j = 0; j < P; ++j) chunk(wa[j], c0 + j);
+        if (c0 + 2 * P < NCHUNK) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) wa[j] = load_chunk(c0 + 2 * P + j);
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) chunk(wb[j], c0 + P + j);
+    }
+    // offset / len (m17_dsp.cpp:213): the row's sum sits in lane 0 of `carry`
+    if (first && valid) {
+        offs[cb] = carry / (float)kBlockSamples;
+        if (update_state && blk == 0) {
+            st[chan].z0re = n0re; st[chan].z0im = n0im; st[chan].z1re = n1re; st[chan].z1im = n1im;
+        }
+    }
+}
+
 // the 16 consecutive rows cb0 .. cb0 + 15 of the row space (rows from `total` on are not stored)
 __device__ __forceinline__ void frontend_d_tile(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
                                                 float *__restrict__ disc_raw, float *__restrict__ offs,

@@ -261,15 +261,18 @@ bool plain_slots(const m17gpu_ctx *ctx, int nblk)
     return fir == 3 || fir == 4;
 }
 // 5: front end, timing loop and framer of a channel on three waves of one workgroup (k_sync_frame_duo<1>) -- small
-// batches, where one channel per SIMD slot leaves both kernels latency-bound: up to 1,024 channels, calls of at least
-// sixteen blocks (the front-end wave's tile is sixteen of the channel's blocks; a shorter call would pay for a whole one)
+// batches, where one channel per SIMD slot leaves both kernels latency-bound: up to 1,024 channels.  Short calls (under
+// sixteen blocks; up to eight start on four-row tiles) at every channel count: one launch instead of two, 10-25 % less
+// from 1 x 1 to 1,024 x 12.  Longer calls from 512 channels on: below, the stand-alone front end spreads a channel's
+// blocks over the idle chip while the channel's own front-end wave takes them tile after tile (256 x 50: +1 %, 1 x 50:
+// +5 %; profiles/r05_three_wave_fir_stage_1024.txt).
 int fir_choice(const m17gpu_ctx *ctx, int nblk)
 {
     if (ctx->afc) return 1;
     const bool trio_ok = (ctx->sync_impl == 0 || ctx->sync_impl == 6) && ctx->C <= 1024 && ctx->slot_impl != 1;
     if (ctx->fir_impl == 5) return trio_ok ? 5 : 1;
     if (ctx->fir_impl != 0) return ctx->fir_impl;
-    if (trio_ok && nblk >= 16) return 5;
+    if (trio_ok && (nblk < 16 || ctx->C >= 512)) return 5;
     return (nblk % 16 == 0 && ctx->C >= 10000) ? 4 : 1;
 }
 int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,

@@ -486,6 +486,17 @@ def test_pluto_decimator_bit_exact_and_streaming():
         rx.close()
 
 
+@pytest.mark.parametrize("nblk", [2, 4, 5, 7, 8, 13])
+def test_short_calls_on_the_three_wave_kernel(nblk):
+    """Calls of up to eight blocks start on four-row tiles (frontend_quick4): rows 0-3 on the front-end wave, 4-7 on
+    the framer wave; the default up to 1,024 channels, and forced here too so that a policy change cannot hide it."""
+    for opts in (None, {"fir_impl": 5}):
+        _rx_compare(C=37, nblk=nblk, mode=1, ebn0=200.0, nsf=10, calls=4, options=opts)
+        _rx_compare(C=21, nblk=nblk, mode=1, ebn0=7.0, nsf=6, calls=3, options=opts)
+    _rx_compare(C=1024, nblk=nblk, mode=1, ebn0=9.0, nsf=12, calls=2)
+    _rx_compare(C=1, nblk=nblk, mode=0, ebn0=200.0, calls=5)
+
+
 def _compare_raw(iq, mode, rec_cap=None, options=None):
     """GPU vs oracle on caller-made IQ.  NaNs (0,0 samples limit to NaN in the reference too)
     compare as equal whatever their payload; everything else bit for bit."""
@@ -540,6 +551,9 @@ def test_hostile_input_zero_saturated_and_noise():
     # the front-end tiles of round 5 (halving at the picks, lane moves folded into the DC chain): zeros make NaNs there too
     for opts in ({"fe_impl": 3}, {"fe_impl": 4}, {"fir_impl": 3}, {"fir_impl": 4}, {"fir_impl": 5}, {"fir_impl": 4, "slot_impl": 2}):
         _compare_raw(np.ascontiguousarray(iq), mode=1, options=opts)
+    # ... and the four-row tiles of short calls (scalar conversion, chain through sixteen lanes)
+    _compare_raw(np.ascontiguousarray(iq[:, :8]), mode=1, options={"fir_impl": 5})
+    _compare_raw(np.ascontiguousarray(iq[:, 2:6]), mode=1)
 
 
 def test_record_capacity_overflow_and_max_blocks():
