@@ -49,7 +49,24 @@ constexpr int FU_WAVES = 4;                    // channels (waves) per workgroup
 constexpr int FU_XF = 2 + (kTaps - 1) + FU_R * kDiscOut + 124 + 4;
 static_assert(FU_XF % 4 == 0 && FU_NCHUNK % (2 * FU_P) == 0, "fused kernel layout");
 
-// (dpp_keep, fu_left, fu_chain: m17_kernels.hip, next to frontend_quick4, which shares them)
+// (dpp_keep, fu_left: m17_kernels.hip, next to frontend_quick4p, which shares them)
+
+// The DC sum of one chunk (m17_dsp.cpp:211: offset += out, strictly in sample order): on entry `carry` holds, in lane
+// 0 of each row, the row's sum so far; u0..u3 the lane's four values, a0..a3 the same with exact zeros in lane 0.
+// Lane 0 finishes in the first four adds; after step j lanes 0..j hold their final sums (lane l <= j recomputes the
+// same value from lane l-1's final one; lane 0 is disabled for the DPP add -- no source, bound_ctrl 0 -- and adds
+// zeros, which is exact: a running sum that starts at +0 never is -0).  Leaves the row's new sum in lane 0 of `carry`.
+// (s_nop 1: a VALU write followed by a DPP read of the same register needs two wait states on gfx9.)
+#define FU_STEP "s_nop 1\n\tv_add_f32_dpp %0, %0, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+                "v_add_f32 %0, %0, %7\n\tv_add_f32 %0, %0, %8\n\tv_add_f32 %0, %0, %9\n\t"
+__device__ __forceinline__ void fu_chain(float &carry, float u0, float u1, float u2, float u3, float a0, float a1, float a2, float a3)
+{
+    float T;
+    asm volatile("v_add_f32 %0, %1, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %0, %0, %4\n\tv_add_f32 %0, %0, %5\n\t"
+                 FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP
+                 "s_nop 1\n\tv_mov_b32_dpp %1, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(T), "+v"(carry) : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+}
 
 __global__ __launch_bounds__(64 * FU_WAVES, 4)
 void k_rx_fused(const uint4 *__restrict__ iq,              // [C][nblk][480] uint4 (4 IQ samples each)

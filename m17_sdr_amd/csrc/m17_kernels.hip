@@ -706,40 +706,45 @@ __device__ __forceinline__ float fu_left(float cur, float prev)
     return dpp_keep<0x111>(t, cur);                       // row_shr:1
 }
 
-// The DC sum of one chunk (m17_dsp.cpp:211: offset += out, strictly in sample order): on entry `carry` holds, in lane
-// 0 of each row, the row's sum so far; u0..u3 the lane's four values, a0..a3 the same with exact zeros in lane 0.
-// Lane 0 finishes in the first four adds; after step j lanes 0..j hold their final sums (lane l <= j recomputes the
-// same value from lane l-1's final one; lane 0 is disabled for the DPP add -- no source, bound_ctrl 0 -- and adds
-// zeros, which is exact: a running sum that starts at +0 never is -0).  Leaves the row's new sum in lane 0 of `carry`.
-// (s_nop 1: a VALU write followed by a DPP read of the same register needs two wait states on gfx9.)
-#define FU_STEP "s_nop 1\n\tv_add_f32_dpp %0, %0, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
-                "v_add_f32 %0, %0, %7\n\tv_add_f32 %0, %0, %8\n\tv_add_f32 %0, %0, %9\n\t"
-__device__ __forceinline__ void fu_chain(float &carry, float u0, float u1, float u2, float u3, float a0, float a1, float a2, float a3)
+// A QUICK tile: FOUR rows of sixteen lanes (k_rx_fused's row mapping, m17_fused.hip, as a device function that stores to
+// the workspace like frontend_tile).  A lone wave needs 23 us for it against 40 for a sixteen-row tile, whatever that
+// holds -- each lane converts 120 samples instead of 480, the 1,920-step DC chain costs the same -- so it is what the
+// front-end wave (and the idle framer wave) of a channel in k_sync_frame_duo<1> run on short calls (round 5).
+//   load    : lane (r, l) of chunk c reads the two uint4 with samples 128c + 8l .. + 7 of row r (512 contiguous bytes per row)
+//   compute : fe_convert<8> (packed fp32, stage by stage) on the lane's own eight samples; the two before them by DPP
+//             row_shr:1 (lane 0: the row's previous chunk); the discriminator without its halving (u2 = 2u: halved at the
+//             picks and at the block's sum; exact, see frontend_lite_tile)
+//   DC sum  : the chain runs lane by lane through the row as 16 x 8 dependent adds per chunk (fu_chain8)
+//   /5 pick : positions s = 128c + 8l + k with s % 5 == 4 are the outputs: with q = (3c + 3l) % 5 the lane's first pick is
+//             its sample k0 = 4 - q, its second one k0 + 5 when k0 <= 2; stored straight to their places in the row
+// rowmap(i, valid), i = 0 .. 3: as for frontend_tile.
+// fu_chain8 (the eight-sample form of fu_chain, m17_fused.hip): on entry `carry` holds, in lane 0 of each row, twice the row's
+// sum so far; u the lane's eight values, a the same with exact zeros in lane 0.  Lane 0 finishes in the first eight adds;
+// after step j lanes 0..j hold their final sums (lane l <= j recomputes the same value from lane l-1's final one; lane 0
+// has no source for the DPP add -- bound_ctrl 0: it keeps its value -- and adds zeros, which is exact: a running sum that
+// starts at +0 never is -0).  Leaves the row's new sum in lane 0 of `carry`.  (s_nop 1: a VALU write followed by a DPP read
+// of the same register needs two wait states on gfx9.)
+#define FU_STEP8 "s_nop 1\n\tv_add_f32_dpp %0, %0, %10 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_add_f32 %0, %0, %11\n\tv_add_f32 %0, %0, %12\n\tv_add_f32 %0, %0, %13\n\tv_add_f32 %0, %0, %14\n\t" \
+                 "v_add_f32 %0, %0, %15\n\tv_add_f32 %0, %0, %16\n\tv_add_f32 %0, %0, %17\n\t"
+__device__ __forceinline__ void fu_chain8(float &carry, const float (&u)[8], const float (&a)[8])
 {
     float T;
     asm volatile("v_add_f32 %0, %1, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %0, %0, %4\n\tv_add_f32 %0, %0, %5\n\t"
-                 FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP FU_STEP
+                 "v_add_f32 %0, %0, %6\n\tv_add_f32 %0, %0, %7\n\tv_add_f32 %0, %0, %8\n\tv_add_f32 %0, %0, %9\n\t"
+                 FU_STEP8 FU_STEP8 FU_STEP8 FU_STEP8 FU_STEP8 FU_STEP8 FU_STEP8 FU_STEP8 FU_STEP8 FU_STEP8 FU_STEP8 FU_STEP8 FU_STEP8 FU_STEP8 FU_STEP8
                  "s_nop 1\n\tv_mov_b32_dpp %1, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
-                 : "=&v"(T), "+v"(carry) : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+                 : "=&v"(T), "+v"(carry)
+                 : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]),
+                   "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
 }
-
-
-// A QUICK tile: FOUR rows of sixteen lanes (k_rx_fused's front-end phase, m17_fused.hip, as a device function that
-// stores to the workspace like frontend_tile).  A lone wave needs ~40 % of a sixteen-row tile's time for it -- each lane
-// converts 120 samples instead of 480, the 1,920-step DC chain costs the same -- so it is what the three waves of a
-// channel in k_sync_frame_duo<1> run first, side by side, to get the timing loop started (round 5).
-//   load    : lane (r, l) of chunk c reads the uint4 with samples 64c + 4l .. + 3 of row r; two register sets of five chunks
-//   compute : the lane's own four samples; the two before them by DPP row_shr:1 (lane 0: the row's previous chunk)
-//   DC sum  : fu_chain; /5 pick: sample s is an output iff s % 5 == 4 -- with q = (c + l) % 5 the lane's pick is its
-//             sample q - 1 (none for q == 0), stored straight to its place in the row
-// rowmap(i, valid), i = 0 .. 3: as for frontend_tile.
 template <class RowMap>
-__device__ __forceinline__ void frontend_quick4(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
-                                                float *__restrict__ disc_raw, float *__restrict__ offs,
-                                                int nblk, int update_state, RowMap rowmap, const int lane)
+__device__ __forceinline__ void frontend_quick4p(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
+                                                 float *__restrict__ disc_raw, float *__restrict__ offs,
+                                                 int nblk, int update_state, RowMap rowmap, const int lane)
 {
-    constexpr int P = 5, NCHUNK = kBlockSamples / 64;
-    static_assert(NCHUNK % (2 * P) == 0, "quick tile passes");
+    constexpr int P = 5, NCHUNK = kBlockSamples / 128;    // 15 chunks, three rounds of five
+    static_assert(NCHUNK % P == 0, "quick tile passes");
     const int r = lane >> 4, l = lane & 15;
     bool valid;
     const int cb = rowmap(r, valid);
@@ -758,59 +763,60 @@ __device__ __forceinline__ void frontend_quick4(const uint4 *__restrict__ iq, Ch
         limit(p3re, p3im);
     }
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-    const uint4 *const rowp = iq + (size_t)cb * (kBlockSamples / 4) + l;
-    auto load_chunk = [&](int c) { return __builtin_nontemporal_load(reinterpret_cast<const u4v *>(rowp + c * 16)); };
+    const uint4 *const rowp = iq + (size_t)cb * (kBlockSamples / 4) + 2 * l;
     float *const dst = disc_raw + (size_t)cb * kDiscOut;
-    float carry = 0.0f;                                    // offset = 0 (m17_dsp.cpp:199)
-    int q = l % 5;                                         // (c + l) % 5
+    float carry = 0.0f;                                    // TWICE the row's DC sum so far, in lane 0 of the row
+    int q = (3 * l) % 5;                                   // (3c + 3l) % 5
     const bool first = l == 0;
-    auto chunk = [&](const u4v v, const int c) {
-        const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
-        float re[4], im[4];
+    auto chunk = [&](const u4v v0, const u4v v1, const int c) {
+        const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        v2f z[8];
+        fe_convert<8>(w, z);
+        const v2f m1 = {fu_left(z[7].x, p3re), fu_left(z[7].y, p3im)};            // sample -1 of this lane's run
+        const v2f m2 = {fu_left(z[6].x, p2re), fu_left(z[6].y, p2im)};            // sample -2
+        p3re = z[7].x; p3im = z[7].y; p2re = z[6].x; p2im = z[6].y;
+        float u2[8], a[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            re[k] = s16_to_float((int)(short)(ww[k] & 0xFFFF));
-            im[k] = s16_to_float((int)ww[k] >> 16);
-            limit(re[k], im[k]);
+        for (int e = 0; e < 8; ++e) {
+            // dsp_arctan_disc2 (m17_dsp.cpp:194-222): z0 = sample e-1, z1 = sample e-2; u2 = 2 u
+            const v2f z0 = (e >= 1) ? z[e >= 1 ? e - 1 : 0] : m1;
+            const v2f z1 = (e >= 2) ? z[e >= 2 ? e - 2 : 0] : (e == 1 ? m1 : m2);
+            const v2f d = z[e] - z1;
+            const v2f pr = d * (v2f){z0.y, z0.x};                                  // (aa, bb)
+            u2[e] = pr.y - pr.x;
+            a[e] = first ? 0.0f : u2[e];
         }
-        const float m1re = fu_left(re[3], p3re), m1im = fu_left(im[3], p3im);     // sample -1 of this lane's run
-        const float m2re = fu_left(re[2], p2re), m2im = fu_left(im[2], p2im);     // sample -2
-        p3re = re[3]; p3im = im[3]; p2re = re[2]; p2im = im[2];
-        float u[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            // dsp_arctan_disc2 (m17_dsp.cpp:194-222): z0 = sample k-1, z1 = sample k-2
-            const float z0re = k >= 1 ? re[k >= 1 ? k - 1 : 0] : m1re, z0im = k >= 1 ? im[k >= 1 ? k - 1 : 0] : m1im;
-            const float z1re = k >= 2 ? re[k >= 2 ? k - 2 : 0] : (k == 1 ? m1re : m2re);
-            const float z1im = k >= 2 ? im[k >= 2 ? k - 2 : 0] : (k == 1 ? m1im : m2im);
-            const float aa = z0im * (re[k] - z1re);
-            const float bb = z0re * (im[k] - z1im);
-            u[k] = (bb - aa) * 0.5f;
+        fu_chain8(carry, u2, a);
+        // count % 5 == 0 picks (m17_dsp.cpp:207-210)
+        const int k0 = q == 0 ? 4 : 4 - q;
+        const float s1 = q == 4 ? u2[0] : (q == 3 ? u2[1] : (q == 2 ? u2[2] : (q == 1 ? u2[3] : u2[4])));
+        const float s2 = q == 4 ? u2[5] : (q == 3 ? u2[6] : u2[7]);
+        const v2f h = (v2f){s1, s2} * (v2f){0.5f, 0.5f};
+        const unsigned oidx = ((unsigned)(128 * c + 8 * l + k0 - 4) * 52429u) >> 18;       // (s - 4) / 5
+        if (valid) {
+            dst[oidx] = h.x;
+            if (q >= 2) dst[oidx + 1] = h.y;
         }
-        fu_chain(carry, u[0], u[1], u[2], u[3], first ? 0.0f : u[0], first ? 0.0f : u[1], first ? 0.0f : u[2], first ? 0.0f : u[3]);
-        const float pick = q == 1 ? u[0] : (q == 2 ? u[1] : (q == 3 ? u[2] : u[3]));
-        const unsigned oidx = ((unsigned)(64 * c + 4 * l + q - 5) * 52429u) >> 18;        // (s - 4) / 5, s = 64c + 4l + q - 1
-        if (q != 0 && valid) dst[oidx] = pick;
-        q = (q == 4) ? 0 : q + 1;
+        q = q >= 2 ? q - 2 : q + 3;
     };
-    u4v wa[P], wb[P];
+    // five chunks of input in flight, each in its own registers: slot j holds chunk c0 + j and is loaded again (chunk
+    // c0 + j + 5) as soon as it has been consumed -- a lone wave streams its rows against the full memory latency
+    auto ld = [&](int c, int half) { return __builtin_nontemporal_load(reinterpret_cast<const u4v *>(rowp + c * 32 + half)); };
+    u4v ws[2 * P];
 #pragma unroll
-    for (int j = 0; j < P; ++j) wa[j] = load_chunk(j);
-    for (int c0 = 0; c0 < NCHUNK; c0 += 2 * P) {
+    for (int j = 0; j < P; ++j) { ws[2 * j] = ld(j, 0); ws[2 * j + 1] = ld(j, 1); }
+    for (int c0 = 0; c0 < NCHUNK; c0 += P) {
 #pragma unroll
-        for (int j = 0; j < P; ++j) wb[j] = load_chunk(c0 + P + j);
-#pragma unroll
-        for (int j = 0; j < P; ++j) chunk(wa[j], c0 + j);
-        if (c0 + 2 * P < NCHUNK) {
-#pragma unroll
-            for (int j = 0; j < P; ++j) wa[j] = load_chunk(c0 + 2 * P + j);
+        for (int j = 0; j < P; ++j) {
+            const u4v v0 = ws[2 * j], v1 = ws[2 * j + 1];
+            const int nx = min(c0 + j + P, NCHUNK - 1);              // behind the row's end: its last chunk again, unused
+            ws[2 * j] = ld(nx, 0); ws[2 * j + 1] = ld(nx, 1);
+            chunk(v0, v1, c0 + j);
         }
-#pragma unroll
-        for (int j = 0; j < P; ++j) chunk(wb[j], c0 + P + j);
     }
-    // offset / len (m17_dsp.cpp:213): the row's sum sits in lane 0 of `carry`
+    // offset / len (m17_dsp.cpp:213): twice the row's sum sits in lane 0 of `carry`
     if (first && valid) {
-        offs[cb] = carry / (float)kBlockSamples;
+        offs[cb] = (carry * 0.5f) / (float)kBlockSamples;
         if (update_state && blk == 0) {
             st[chan].z0re = n0re; st[chan].z0im = n0im; st[chan].z1re = n1re; st[chan].z1im = n1im;
         }

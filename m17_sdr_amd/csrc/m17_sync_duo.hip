@@ -119,16 +119,16 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
         auto rows_from = [&](int r0) {
             return [=](int i, bool &valid) { valid = r0 + i < bcount; return chan * nblk + b0 + (valid ? r0 + i : bcount - 1); };
         };
-        // Short calls (up to eight blocks): four-row tiles (frontend_quick4: 30 us on a lone wave against 40 for a
+        // Short calls (up to eight blocks): four-row tiles (frontend_quick4p: 23 us on a lone wave against 40 for a
         // sixteen-row tile, whatever that holds), rows 0-3 on the front-end wave and rows 4-7 on the framer wave, which has
         // nothing to frame yet.  Longer calls gain nothing from a quick start -- the timing wave would catch up with the
-        // front-end wave inside its first sixteen-row tile and wait there (measured: three quick tiles in front of the
-        // sixteen-row ones +5 % at 12-50 blocks, profiles/r05_three_wave_fir_stage_1024.txt).
+        // front-end wave inside its first sixteen-row tile and wait there (measured: three four-row tiles in front of the
+        // sixteen-row ones +4-5 % at 12-50 blocks, profiles/r05_three_wave_fir_stage_1024.txt).
         const bool short_call = bcount <= 8;
         if (wave >= 8) {
             // =========================== front-end wave ===========================
             if (short_call) {
-                frontend_quick4(iq, st, disc_w, offs_w, nblk, 1, rows_from(0), gl);
+                frontend_quick4p(iq, st, disc_w, offs_w, nblk, 1, rows_from(0), gl);
                 duo_post(&my.fe_rows, min(4, bcount), gl);
                 return;
             }
@@ -139,7 +139,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
             return;
         }
         if (is_framer && short_call && bcount > 4) {
-            frontend_quick4(iq, st, disc_w, offs_w, nblk, 1, rows_from(4), gl);
+            frontend_quick4p(iq, st, disc_w, offs_w, nblk, 1, rows_from(4), gl);
             duo_wait(&my.fe_rows, 4);                   // one counter, two writers: this one second
             duo_post(&my.fe_rows, bcount, gl);
         }

@@ -488,7 +488,7 @@ def test_pluto_decimator_bit_exact_and_streaming():
 
 @pytest.mark.parametrize("nblk", [2, 4, 5, 7, 8, 13])
 def test_short_calls_on_the_three_wave_kernel(nblk):
-    """Calls of up to eight blocks start on four-row tiles (frontend_quick4): rows 0-3 on the front-end wave, 4-7 on
+    """Calls of up to eight blocks start on four-row tiles (frontend_quick4p): rows 0-3 on the front-end wave, 4-7 on
     the framer wave; the default up to 1,024 channels, and forced here too so that a policy change cannot hide it."""
     for opts in (None, {"fir_impl": 5}):
         _rx_compare(C=37, nblk=nblk, mode=1, ebn0=200.0, nsf=10, calls=4, options=opts)
