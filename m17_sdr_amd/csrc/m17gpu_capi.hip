@@ -273,7 +273,11 @@ int fir_choice(const m17gpu_ctx *ctx, int nblk)
     if (ctx->fir_impl == 5) return trio_ok ? 5 : 1;
     if (ctx->fir_impl != 0) return ctx->fir_impl;
     if (trio_ok && (nblk < 16 || ctx->C >= 512)) return 5;
-    return (nblk % 16 == 0 && ctx->C >= 10000) ? 4 : 1;
+    // 4: the wave-per-channel stage works in tiles of sixteen of the channel's blocks, a partial last tile costs a whole one:
+    // it wins while the call fills at least five sixths of its tiles (14-16, 27-32, 40-48, 54- blocks; measured at 16,384
+    // channels: 12 blocks even, 20: +5 %, 24: +2 %, 40: -3 %, 16: -8 %; profiles/r05_channel_count_crossover.txt)
+    const int tiles16 = (nblk + 15) & ~15;
+    return (ctx->C >= 10000 && tiles16 * 5 <= nblk * 6) ? 4 : 1;
 }
 int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
                  int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st)
