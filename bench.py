@@ -223,10 +223,13 @@ def cpu_baseline(mode, sig):
         if best is None or v > best[0]:
             best = (v, t, t_used, reps)
     ch1 = oracle.Channels(1)                        # single-thread figure, to set beside SURVEY's 47.8 us/block
-    t1 = time.perf_counter()
-    for _ in range(8):
+    best1 = None                                    # the fastest of eight passes: behind the 256-thread leg the first ones can
+    for _ in range(8):                              # find the job's CPU quota spent (seen once: 749 us/block instead of 19)
+        t1 = time.perf_counter()
         ch1.rx_blocks(iq[:1], mode=mode, want_syms=False, nthreads=1)
-    us_blk = (time.perf_counter() - t1) / (8 * iq.shape[1]) * 1e6
+        dt = time.perf_counter() - t1
+        best1 = dt if best1 is None or dt < best1 else best1
+    us_blk = best1 / iq.shape[1] * 1e6
     v, cores, t_used, reps = best
     return {"value": round(v, 3), "unit": "Msym/s", "cores": cores, "kind": "port",
             "host": {"threads_usable_by_this_job": avail, "physical_cores": phys, "hardware_threads": smt,
