@@ -24,6 +24,9 @@ def _draw(rng):
     nblk = int(rng.choice([1, 2, 5, 12, 15, 16, 17, 31, 32, 33, 48])) if rng.random() < 0.7 else int(rng.integers(1, 49))
     if C * nblk > 40000:                                   # keeps a trial (generator + oracle on the host) near a second
         nblk = max(1, 40000 // C)
+    if rng.random() < 0.02:                                # now and then a batch of the size the wave-per-channel kernels are chosen for
+        C = int(rng.choice([8192, 10000, 10240, 12001]))
+        nblk = int(rng.choice([12, 14, 16, 27, 32]))
     mode = int(rng.random() < 0.75)
     calls = int(rng.choice([1, 1, 2, 3]))
     ebn0 = float(rng.choice([200.0, 15.0, 9.0, 6.0, 4.0]))
@@ -68,6 +71,8 @@ def test_random_shapes_conditions_and_variants_are_bit_exact():
         except AssertionError as e:
             raise AssertionError(f"trial {trials} {p}: {str(e)[:2000]}") from None
         trials += 1
+        if trials % 100 == 0:                              # a long run must be seen to be alive
+            print(f"fuzz: {trials} trials, {time.time() - t0:.0f} s", flush=True)
     print(f"fuzz: {trials} trials ({raw} on mutilated input) in {time.time() - t0:.1f} s, seed "
           f"{os.environ.get('M17_FUZZ_SEED', '5')}")
     assert trials >= 3
