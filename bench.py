@@ -386,8 +386,9 @@ def noisy_leg(args, torch, device, C, nblk, ebn0=8.0):
 
 def step12_leg(args, torch, device, C, nblk=12):
     """The headline step of rounds 1-4 -- full chain, 16,384 channels x TWELVE blocks, noiseless -- kept on the line so that
-    the rounds stay comparable.  (Twelve blocks are not whole sixteen-block tiles: the library runs front end + timing
-    kernel as two launches here.)"""
+    the rounds stay comparable.  (Twelve blocks are no whole sixteen-block tile: since the end of round 5 the wave-per-channel
+    stage packs the rows of a workgroup's four channels into three tiles here; until then front end + timing kernel ran as
+    two launches.)"""
     import m17_sdr_amd as m
     steps, warm = 20, 3
     rx = m.Receiver(C, nblk, device=device)

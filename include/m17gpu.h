@@ -150,13 +150,13 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  *                            channel-block, 3 = four lanes with the DC chain and the /5 pick in registers,
  *                            4 = the same on 32-sample chunks (76 VGPRs, 4.6 KB of LDS: the tile of k_rx_chan6)
  *   "fir_impl"           0 = by call (default): 5 up to 1,024 channels (calls of >= 16 blocks: from 512 channels on),
- *                            4 on >= 10,000 channels for calls that fill at least five sixths of their sixteen-block
- *                            tiles (14-16, 27-32, 40-48, 54- blocks), else 1;
+ *                            4 on >= 10,000 channels for calls of >= 12 blocks, else 1;
  *                            1 = front end and timing / framer as two kernels; 2 = the whole FIR stage of a
  *                            channel in one wave, four blocks at a time through LDS (k_rx_fused: no discriminator rows
  *                            in HBM; measured slower); 3 = a wave per channel that runs the front
  *                            end over sixteen of its own blocks at a time and the timing loop / framer behind it, the
- *                            rows through the workspace (k_rx_chan); 4 = that built for six waves per SIMD (k_rx_chan6);
+ *                            rows through the workspace (k_rx_chan); 4 = that built for six waves per SIMD (k_rx_chan6; a last
+ *                            group of fewer than sixteen blocks shares its tiles among the four channels of a workgroup);
  *                            5 = up to 1,024 channels: front end, timing loop and framer of a channel on three waves of
  *                            one workgroup, the front end sixteen blocks ahead of the timing loop (k_sync_frame_duo<1>;
  *                            calls of up to eight blocks start on four-row tiles; falls back to 1 where the two-wave

@@ -312,8 +312,8 @@ void k_rx_chan(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float *
 }
 
 
-// k_rx_chan6 (round 5; option fir_impl 4; the library's choice from 10,000 channels on for calls of whole sixteen-block
-// groups): k_rx_chan built for SIX waves per SIMD -- frontend_lite_tile (32-sample chunks, ~60 VGPRs, 4.6 KB of LDS) and the
+// k_rx_chan6 (round 5; option fir_impl 4; the library's choice from 10,000 channels on for calls of at least twelve
+// blocks): k_rx_chan built for SIX waves per SIMD -- frontend_lite_tile (32-sample chunks, ~60 VGPRs, 4.6 KB of LDS) and the
 // timing loop with taps and window through half the registers (sync_wave_channel<1>).  Measured: the
 // same time as k_rx_chan at four waves per SIMD -- the stage is bound by the vector ALU (~76 % busy) and by its traffic
 // past L2 (4.7-5.1 TB/s), not by what more waves would cover; it is the default of the two for the registers and LDS it
@@ -327,8 +327,9 @@ void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float 
 {
     __shared__ __attribute__((aligned(4096))) unsigned char lds[RC_WAVES][RC6_LDS];
     const int wave = uni((int)(threadIdx.x >> 6));
-    const int chan = (int)blockIdx.x * RC_WAVES + wave;
-    if (chan >= C) return;
+    const int chan0 = (int)blockIdx.x * RC_WAVES;      // the workgroup's first channel (always < C)
+    const int chan = chan0 + wave;
+    const bool live = chan < C;                         // no early exit: a group of fewer than sixteen blocks has a workgroup barrier
     uint32_t *tile = reinterpret_cast<uint32_t *>(lds[wave]);
     float *otile = reinterpret_cast<float *>(lds[wave] + FL_TILE_BYTES);
     WvChan &wc = *reinterpret_cast<WvChan *>(lds[wave]);
@@ -340,18 +341,39 @@ void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float 
     for (int b0 = 0; b0 < nblk; b0 += 16) {
         const int bc = min(16, nblk - b0);
         float *const dw = disc, *const ow = offs;
-        // rows b0 .. b0 + 15 of this channel (rows past its last block are computed on its last row and never stored)
-        frontend_lite_tile(iq, st, dw, ow, nblk, 1,
-                                 [&](int i, bool &valid) { valid = i < bc; return row0 + b0 + (valid ? i : bc - 1); }, tile, otile, rc_lane());
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the rows are in memory before this wave reads them back
-        wave_lds_sync();
+        if (bc == 16) {
+            // rows b0 .. b0 + 15 of this channel: written and read back by the same wave
+            if (live) {
+                frontend_lite_tile(iq, st, dw, ow, nblk, 1, [&](int i, bool &valid) { valid = true; return row0 + b0 + i; }, tile, otile, rc_lane());
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the rows are in memory before this wave reads them back
+                wave_lds_sync();
+            }
+        } else {
+            // A last group of fewer than sixteen blocks: a tile costs the same whatever it holds, so the 4 x bc rows of the
+            // workgroup's four channels are packed into ceil(bc / 4) tiles on its first waves -- row j of that list is block
+            // b0 + j % bc of channel chan0 + j / bc -- and every wave reads its channel's rows back behind a workgroup barrier
+            // (same CU: the rows are whole cache lines nobody has read yet; the offsets are read at agent scope).
+            const int ntile = (RC_WAVES * bc + 15) >> 4;
+            if (wave < ntile) {
+                frontend_lite_tile(iq, st, dw, ow, nblk, 1,
+                                   [&](int i, bool &valid) {
+                                       const int j = 16 * wave + i, cj = j / bc, ch = chan0 + cj;
+                                       valid = cj < RC_WAVES && ch < C;
+                                       return valid ? ch * nblk + b0 + (j - cj * bc) : chan0 * nblk + b0;
+                                   }, tile, otile, rc_lane());
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        }
 #ifdef M17_STAMPS
         { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fe += now - t_last; t_last = now; }
 #endif
-        sync_wave_channel<1>(dw, ow, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, bc,
-                                chan, wc, wave, rc_lane());
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // channel state out before the next group reads it
-        wave_lds_sync();
+        if (live) {
+            sync_wave_channel<1, 1>(dw, ow, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, bc,
+                                    chan, wc, wave, rc_lane());
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // channel state out before the next group reads it
+            wave_lds_sync();
+        }
 #ifdef M17_STAMPS
         { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_tm += now - t_last; t_last = now; }
 #endif

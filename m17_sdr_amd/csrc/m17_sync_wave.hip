@@ -337,7 +337,10 @@ __device__ __forceinline__ void wv_store_state(const WvCtl &t, ChanState &cs, in
 
 // the whole call of ONE channel by the calling wave; `my` = the channel's 4 KB of LDS (4 KB-aligned), wave = the wave's
 // index in its workgroup (instrumented build only)
-template <int HALF = 0>
+// OFFS_AGENT: the block offsets are read past the CU's caches (agent scope) -- for a caller whose rows were written in
+// this kernel by ANOTHER wave of the workgroup (k_rx_chan6's shared tiles): thirty-two offsets share a 128-byte line, and a
+// line this wave read for an earlier group must not be served again once a sibling has written the next group's part of it.
+template <int HALF = 0, int OFFS_AGENT = 0>
 __device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc, const float *__restrict__ offs,
                        ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
                        m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
@@ -370,8 +373,12 @@ __device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc
     if (gl < kTaps - 1) my.x[gl] = cs.buff[gl + 1];
     const float *dsrc = disc + (size_t)chan * nblk * kDiscOut;
     const float *osrc = offs ? offs + (size_t)chan * nblk : nullptr;
+    auto ld_off = [&](int b) {
+        if constexpr (OFFS_AGENT) return __hip_atomic_load(&osrc[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return osrc[b];
+    };
     {
-        const float off = osrc ? osrc[b0] : 0.0f;
+        const float off = osrc ? ld_off(b0) : 0.0f;
 #pragma unroll
         for (int r = 0; r < kDiscOut / LPC; ++r) {
             float v = __builtin_nontemporal_load(&dsrc[(size_t)b0 * kDiscOut + gl + LPC * r]);
@@ -404,7 +411,7 @@ __device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc
         float noff = 0.0f;
         if (b + 1 < bend) {
             const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
-            noff = osrc ? osrc[b + 1] : 0.0f;
+            noff = osrc ? ld_off(b + 1) : 0.0f;
 #pragma unroll
             for (int r = 0; r < PF; ++r) pf[r] = __builtin_nontemporal_load(&nx[gl + LPC * r]);   // read once
         }

@@ -273,11 +273,11 @@ int fir_choice(const m17gpu_ctx *ctx, int nblk)
     if (ctx->fir_impl == 5) return trio_ok ? 5 : 1;
     if (ctx->fir_impl != 0) return ctx->fir_impl;
     if (trio_ok && (nblk < 16 || ctx->C >= 512)) return 5;
-    // 4: the wave-per-channel stage works in tiles of sixteen of the channel's blocks, a partial last tile costs a whole one:
-    // it wins while the call fills at least five sixths of its tiles (14-16, 27-32, 40-48, 54- blocks; measured at 16,384
-    // channels: 12 blocks even, 20: +5 %, 24: +2 %, 40: -3 %, 16: -8 %; profiles/r05_channel_count_crossover.txt)
-    const int tiles16 = (nblk + 15) & ~15;
-    return (ctx->C >= 10000 && tiles16 * 5 <= nblk * 6) ? 4 : 1;
+    // 4: the wave-per-channel stage works in tiles of sixteen of the channel's blocks; a last group of fewer blocks is packed
+    // four channels to a workgroup's tiles (k_rx_chan6), so any call from twelve blocks on is served at the cost its rows
+    // need (measured at 16,384 channels: 12 blocks -3 %, 20: -6 %, 24: -6 %, 40: -7 %, 8: even, 10: +3 %;
+    // profiles/r05_channel_count_crossover.txt)
+    return (ctx->C >= 10000 && nblk >= 12) ? 4 : 1;
 }
 int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
                  int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st)

@@ -321,7 +321,7 @@ def test_config5_total_channel_count_on_one_gpu_bit_exact():
     rx.close()
 
 
-@pytest.mark.parametrize("C,nblk", [(1024, 120), (2500, 60), (5003, 30), (10240, 14), (10003, 44)])   # the last two: k_rx_chan6 with a partial last tile
+@pytest.mark.parametrize("C,nblk", [(1024, 120), (2500, 60), (5003, 30), (10240, 14), (10003, 44), (10241, 21), (12002, 12)])   # from 10,000 channels: k_rx_chan6, the last group's tiles shared by the four channels of a workgroup
 def test_long_calls_and_ragged_counts_bit_exact(C, nblk):
     """Many blocks per call (4.8 s of signal in one launch: the symbol ring of the two-wave kernel wraps several
     times, record capacity 2*nblk+2 is used in full) and channel counts that are no multiple of the channels per wave
