@@ -27,3 +27,7 @@ tot = per.sum(1)
 for c in (int(tot.argmin()), int(tot.argmax())):
     print(f"channel {c}: ticks per block (c = taken as calm, x = a branch step in it, L = in lock):")
     print("  " + "  ".join(f"{int(per[c, b])}{'c' if flg[c, b] & 1 else ''}{'x' if flg[c, b] & 2 else ''}{'L' if flg[c, b] & 4 else ''}" for b in range(per.shape[1])))
+# where the timing waves' time goes, over the first 64 channels: calm blocks, blocks with branch steps in lock, unlocked blocks
+calm = (flg & 1) != 0; stepx = (flg & 2) != 0; lock = (flg & 4) != 0
+for name, sel in (("calm, no step", calm & ~stepx), ("locked, with steps", lock & stepx), ("unlocked", ~lock)):
+    print(f"  {name:20s}: {int(sel.sum()):5d} blocks of {sel.size}, {100.0 * per[sel].sum() / per.sum():5.1f} % of the ticks, {per[sel].mean() if sel.any() else 0:8.0f} ticks per block")
