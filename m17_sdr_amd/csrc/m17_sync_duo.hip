@@ -152,14 +152,16 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
 #endif
     if (!is_framer) {
         // =========================== timing wave ===========================
-        int clk = cs.clk, thr = cs.thr, index = cs.index;
-        float sum = cs.sum, dif = cs.dif;
-        int known_lock = cs.flock;
+        // the control state of a channel is wave-uniform: read into scalar registers, so that the branches on it are scalar
+        // branches and its arithmetic the scalar unit's (as loaded -- per lane -- every compare below was an exec-mask branch)
+        int clk = uni(cs.clk), thr = uni(cs.thr), index = uni(cs.index);
+        float sum = unif(cs.sum), dif = unif(cs.dif);
+        int known_lock = uni(cs.flock);
         int hp = 256;
         for (int q = gl; q < kTaps - 1; q += LPC) my.x[q] = cs.buff[q + 1];
         const float *dsrc = disc + (size_t)chan * nblk * kDiscOut;
         const float *osrc = offs ? offs + (size_t)chan * nblk : nullptr;
-        if constexpr (PIPE) { duo_wait(&my.fe_rows, 1); fe_seen = lds_peek(&my.fe_rows); }
+        if constexpr (PIPE) { duo_wait(&my.fe_rows, 1); fe_seen = uni(lds_peek(&my.fe_rows)); }
         {
             const float off = osrc ? duo_offs<PIPE>(&osrc[b0]) : 0.0f;
             for (int q = gl; q < kDiscOut; q += LPC) {
@@ -179,7 +181,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
             float noff = 0.0f;
             if (b + 1 < bend) {
                 if constexpr (PIPE) {
-                    if (b + 1 - b0 >= fe_seen) { duo_wait(&my.fe_rows, b + 2 - b0); fe_seen = lds_peek(&my.fe_rows); }
+                    if (b + 1 - b0 >= fe_seen) { duo_wait(&my.fe_rows, b + 2 - b0); fe_seen = uni(lds_peek(&my.fe_rows)); }
                 }
                 const float *nx = dsrc + (size_t)(b + 1) * kDiscOut;
                 noff = osrc ? duo_offs<PIPE>(&osrc[b + 1]) : 0.0f;
@@ -331,7 +333,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                 if (b > b0) {
                     duo_wait_lds(frm_blk, b - b0);
                     STAMP(1);
-                    actual = lds_peek(&my.lock_after[(b - 1) & 3]);
+                    actual = uni(lds_peek(&my.lock_after[(b - 1) & 3]));
                 }
                 if (actual == lockv) break;
                 lockv = actual;                                       // mispredicted (lock just changed): run the block again
@@ -367,10 +369,10 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
     // =========================== framer wave ===========================
     m17gpu_rec_dev *crecs = recs ? recs + (size_t)chan * rec_cap : nullptr;
     if (!recs) rec_cap = 0;
-    int flock = cs.flock, fclk = cs.fclk, ferr = cs.ferr;
-    uint32_t block_count = cs.block_count;
-    int nrec = (b0 == 0) ? 0 : counts[chan];
-    int sym_total = (b0 == 0) ? 0 : cs.sym_total;
+    int flock = uni(cs.flock), fclk = uni(cs.fclk), ferr = uni(cs.ferr);
+    uint32_t block_count = (uint32_t)uni((int)cs.block_count);
+    int nrec = (b0 == 0) ? 0 : uni(counts[chan]);
+    int sym_total = (b0 == 0) ? 0 : uni(cs.sym_total);
     int hp = 256;
     RegroupLane<LPC> rg;
     rg.load(gl);
@@ -385,7 +387,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
         STAMP(2);
         duo_wait<8>(tim_blk, b - b0 + 1);
         STAMP(3);
-        const int n = lds_peek(&my.nsym[b & 3]);
+        const int n = uni(lds_peek(&my.nsym[b & 3]));
         if (sym_out) {
 #pragma unroll
             for (int r = 0; r < (193 + LPC - 1) / LPC; ++r) {
