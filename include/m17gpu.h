@@ -100,6 +100,9 @@ int  m17gpu_channels(const m17gpu_ctx *ctx);
 int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
                      m17gpu_rec *d_recs, int rec_cap, int32_t *d_counts,
                      float *d_syms, int32_t *d_nsyms, void *stream);
+/* Ordering: the calls of ONE context must be ordered on the device -- made on one stream, or on streams the caller has
+ * ordered with events: a call reads the channel state its predecessor wrote, and the work-list counters of a full-chain
+ * call are left zeroed for the next one by its last kernel.  Contexts are independent of each other. */
 
 /* ---------------- stage entry points (batched reference functions) -------- */
 /* dsp_short_to_float + dsp_limit + dsp_arctan_disc2 (m17_dsp.cpp:136-141,
@@ -144,23 +147,24 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  *   "sync_impl"          0 | 6 = by size (default): timing wave + framer wave per channel, decoupled by one
  *                            block, up to 1,024 channels; beyond, one wave per channel with scalar control and the
  *                            filter taps in SGPRs, taps and window through half the registers at eight waves per
- *                            SIMD; 8 = that kernel at every size, 9 = the same at six waves per SIMD, 7 = round 3's
- *                            form of it (all 62 tap registers at once, six waves per SIMD)
- *   "fe_impl"            0 = by size (default), 1 = lane per channel-block, 2 = four lanes per
- *                            channel-block, 3 = four lanes with the DC chain and the /5 pick in registers,
- *                            4 = the same on 32-sample chunks (76 VGPRs, 4.6 KB of LDS: the tile of k_rx_chan6)
+ *                            SIMD; 8 = that kernel at every size
+ *   "fe_impl"            the stand-alone front end (fir_impl 1): 0 | 2 = four lanes per channel-block (default);
+ *                            3 / 4 = the sixteen-row tiles the fused kernels run (k_sync_frame_duo<1>'s on 64-sample
+ *                            chunks, k_rx_chan6's on 32-sample chunks) as kernels of their own, so that each tile is
+ *                            held to the oracle by itself through m17gpu_frontend
  *   "fir_impl"           0 = by call (default): 5 up to 1,024 channels (calls of >= 16 blocks: from 512 channels on),
  *                            4 on >= 10,000 channels for calls of >= 12 blocks, else 1;
- *                            1 = front end and timing / framer as two kernels; 2 = the whole FIR stage of a
- *                            channel in one wave, four blocks at a time through LDS (k_rx_fused: no discriminator rows
- *                            in HBM; measured slower); 3 = a wave per channel that runs the front
+ *                            1 = front end and timing / framer as two kernels; 4 = a wave per channel that runs the front
  *                            end over sixteen of its own blocks at a time and the timing loop / framer behind it, the
- *                            rows through the workspace (k_rx_chan); 4 = that built for six waves per SIMD (k_rx_chan6; a last
- *                            group of fewer than sixteen blocks shares its tiles among the four channels of a workgroup);
+ *                            rows through the workspace, six waves per SIMD (k_rx_chan6; a last group of fewer than
+ *                            sixteen blocks shares its tiles among the four channels of a workgroup);
  *                            5 = up to 1,024 channels: front end, timing loop and framer of a channel on three waves of
  *                            one workgroup, the front end sixteen blocks ahead of the timing loop (k_sync_frame_duo<1>;
  *                            calls of up to eight blocks start on four-row tiles; falls back to 1 where the two-wave
  *                            timing kernel does not apply)
+ *   "order_impl"         dispatch order of k_rx_chan6's waves: 0 = by measurement (default), 1 = channel order, 2 = by
+ *                            the work each channel's last call took, heaviest first (k_order) -- the launch then ends
+ *                            on its cheapest waves; per-channel results do not depend on it
  *   "slot_impl"          how the framer hands a stream frame to the decoder: 1 = its 192 symbols (768 B; the decoder stages
  *                            them in LDS), 2 = regrouped into the order the decoder reads (1,600 B), 0 = by path (default):
  *                            1 behind the wave-per-channel FIR stage, 2 behind front end + timing kernel
@@ -203,6 +207,15 @@ int m17gpu_get_counters(m17gpu_ctx *ctx, uint32_t *h_cnt /* [C][4] */);
 int m17gpu_get_afc(m17gpu_ctx *ctx, float *h_delta /* [C] */);
 /* m17_rx_lock() of every channel (m17_rx_frame.cpp:187-189) */
 int m17gpu_get_lock(m17gpu_ctx *ctx, uint8_t *h_lock /* [C] */);
+/* The timing loop's and the framer's control state of every channel, for inspection / tests:
+ *   h_int [C][6]  = m_clk, m_thr, m_index (m17_rx_sync.cpp:6-9), m_flock, m_fclk, m_frame_errors (m17_rx_frame.cpp:16-18)
+ *   h_flt [C][36] = sum, dif (m17_rx_sync.cpp:78), z[0].re, z[0].im, z[1].re, z[1].im (m17_dsp.cpp:196), m_buff[1 .. 30]
+ *                   (m17_rx_sync.cpp:11; m_buff[0] leaves the window with the next input and is not kept) */
+int m17gpu_get_timing_state(m17gpu_ctx *ctx, int32_t *h_int, float *h_flt);
+/* What the last m17gpu_rx_blocks call ran (the library picks its kernels by call): h_path[0] = FIR stage ("fir_impl"
+ * value: 1, 4, 5), [1] = stream frame slots plain (1) or regrouped (0), [2] = bookkeeping kernel (1 wave / 2 lane per
+ * channel, 0 = none: mode 0), [3] = k_rx_chan6 dispatched by cost (1) or in channel order (0). */
+int m17gpu_get_last_path(const m17gpu_ctx *ctx, int h_path[4]);
 /* host copies of the uploaded tables, for inspection / tests */
 int m17gpu_get_taps(float *h_mf /* [40][31] */, float *h_md /* [40][31] */);
 int m17gpu_get_golay_tables(uint16_t *h_enc /* [4096] */, uint16_t *h_err /* [4096] */);

@@ -65,6 +65,8 @@ SIGNATURES = {
     "m17gpu_get_counters": (_i, [_vp, _vp]),
     "m17gpu_get_lock": (_i, [_vp, _vp]),
     "m17gpu_get_afc": (_i, [_vp, _vp]),
+    "m17gpu_get_timing_state": (_i, [_vp, _vp, _vp]),
+    "m17gpu_get_last_path": (_i, [_vp, _vp]),
     "m17gpu_get_taps": (_i, [_vp, _vp]),
     "m17gpu_get_golay_tables": (_i, [_vp, _vp]),
     "m17gpu_get_constant": (_i, [C.c_char_p, _vp, _i]),

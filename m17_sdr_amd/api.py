@@ -321,6 +321,25 @@ class Receiver:
         _check(lib().m17gpu_get_afc(self._ctx, a.ctypes.data_as(C.c_void_p)), "m17gpu_get_afc")
         return a
 
+    def timing_state(self):
+        """Timing-loop / framer control state per channel under the reference's names (m17_rx_sync.cpp:6-11,78,
+        m17_rx_frame.cpp:16-18, m17_dsp.cpp:196): dict of arrays [C, ...]; m_buff is [C, 31] with column 0 zero (the
+        library keeps m_buff[1 .. 30]: element 0 leaves the window with the next input)."""
+        ai = np.zeros((self.C, 6), np.int32)
+        af = np.zeros((self.C, 36), np.float32)
+        _check(lib().m17gpu_get_timing_state(self._ctx, ai.ctypes.data_as(C.c_void_p), af.ctypes.data_as(C.c_void_p)),
+               "m17gpu_get_timing_state")
+        buff = np.zeros((self.C, 31), np.float32)
+        buff[:, 1:] = af[:, 6:36]
+        return {"m_clk": ai[:, 0], "m_thr": ai[:, 1], "m_index": ai[:, 2], "m_flock": ai[:, 3], "m_fclk": ai[:, 4],
+                "m_frame_errors": ai[:, 5], "sum": af[:, 0].copy(), "dif": af[:, 1].copy(), "z": af[:, 2:6].copy(), "m_buff": buff}
+
+    def last_path(self):
+        """What the last rx_blocks call ran: dict(fir=1|4|5, plain_slots, book=0|1|2, ordered) (m17gpu_get_last_path)."""
+        a = (C.c_int * 4)()
+        _check(lib().m17gpu_get_last_path(self._ctx, a), "m17gpu_get_last_path")
+        return {"fir": a[0], "plain_slots": a[1], "book": a[2], "ordered": a[3]}
+
     def lock(self):
         a = np.zeros((self.C,), np.uint8)
         _check(lib().m17gpu_get_lock(self._ctx, a.ctypes.data_as(C.c_void_p)), "m17gpu_get_lock")

@@ -134,7 +134,13 @@ void k_worklist(const m17gpu_rec_dev *__restrict__ recs, int rec_cap, const int3
         for (int w = 0; w < 16; ++w) wbase[k][w] += base;
     }
     __syncthreads();
-    if (ty) work[(size_t)(ty - 1) * cap + wbase[ty - 1][wave] + (int)__popcll(m[ty - 1] & below)] = (int32_t)i;
+    // (idx < cap always holds when the counters were zero on entry -- a list has at most one entry per record slot; the
+    //  bound keeps a call that found them non-zero, e.g. behind a call that failed between this kernel and the
+    //  bookkeeping kernel that resets them, from writing past its list: m17gpu_rx_blocks also zeroes them in that case)
+    if (ty) {
+        const int idx = wbase[ty - 1][wave] + (int)__popcll(m[ty - 1] & below);
+        if (idx < cap) work[(size_t)(ty - 1) * cap + idx] = (int32_t)i;
+    }
 }
 
 // One frame type per pass: `type` is wave-uniform (a template constant for the stream kernel), so trellis length,
@@ -438,7 +444,7 @@ __device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES, NSYM> &sh
     // before the tables are filled -- the any-type kernel normally finds its lists empty
     {
         int m1 = 0, m2 = 0, m3 = 0;
-        if (work) { m1 = nwork[0]; m2 = nwork[1]; m3 = nwork[2]; }
+        if (work) { m1 = min(nwork[0], cap); m2 = min(nwork[1], cap); m3 = min(nwork[2], cap); }
         if (ONLY == 0 && skip_stream) m2 = 0;
         const int tasks = ONLY ? (m2 + DQ_FRAMES - 1) / DQ_FRAMES
                                : (work ? (m1 + DQ_FRAMES - 1) / DQ_FRAMES + (m2 + DQ_FRAMES - 1) / DQ_FRAMES + (m3 + DQ_FRAMES - 1) / DQ_FRAMES
@@ -458,7 +464,7 @@ __device__ __forceinline__ void decode_quad_body(DqShared<ONLY, WAVES, NSYM> &sh
     __syncthreads();                                                        // the only workgroup barrier: tables are read-only from here
 
     int n1 = 0, n2 = 0, n3 = 0;
-    if (work) { n1 = nwork[0]; n2 = nwork[1]; n3 = nwork[2]; }
+    if (work) { n1 = min(nwork[0], cap); n2 = min(nwork[1], cap); n3 = min(nwork[2], cap); }     // a list never holds more than its capacity (k_worklist)
     if (ONLY == 0 && skip_stream) n2 = 0;
     const int t2 = (n2 + DQ_FRAMES - 1) / DQ_FRAMES, t1 = (n1 + DQ_FRAMES - 1) / DQ_FRAMES,
               t3 = (n3 + DQ_FRAMES - 1) / DQ_FRAMES;

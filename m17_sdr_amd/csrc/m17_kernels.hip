@@ -6,7 +6,7 @@
 //
 //   k_frontend_q      a3+a5+a6   int16 IQ -> limiter -> discriminator -> /5 -> DC sum      (this file)
 //                     16 (channel, block) rows per wave, 4 lanes per row; the 1920-term DC sum is a
-//                     strict sequential fp32 chain, one per row.  k_frontend: one lane per row.
+//                     strict sequential fp32 chain, one per row.
 //   k_sync_frame_*    a9+a11+a12 timing recovery + sync correlator + framer                (m17_sync_*.hip)
 //   k_worklist, k_decode_quad    a14..a24 demap / gather / Viterbi / Golay / packers       (m17_decode_quad.hip)
 //   k_book_chan       a25 etc.   per-channel in-order LICH/LSF/packet bookkeeping          (m17_book.hip)
@@ -150,15 +150,8 @@ __global__ void k_selftest_limit(unsigned *bad)
 }
 
 // ---------------------------------------------------------------------------
-// k_frontend
+// front end
 // ---------------------------------------------------------------------------
-constexpr int FE_CHUNK   = 20;               // samples per LDS chunk: lcm(4 samples/uint4, /5 decimation)
-constexpr int FE_STRIDE  = FE_CHUNK;         // dwords per LDS row; 20 = 4*5 (odd multiple of 4): the 16
-                                             // lanes of a ds_read_b128 group tile all 64 banks
-constexpr int FE_NCHUNK  = kBlockSamples / FE_CHUNK;   // 96
-constexpr int FE_LOADS   = FE_CHUNK / 4;     // uint4 loads per lane per chunk = 5
-constexpr int FE_WAVES   = 4;
-
 __device__ __forceinline__ void wave_lds_sync()
 {
     // LDS traffic of one wave executes in order; this only pins the compiler
@@ -179,111 +172,9 @@ __device__ __forceinline__ void fe_next_z(const uint4 *iq, int cb, int nblk, flo
     limit(z0re, z0im);
 }
 
-__global__ __launch_bounds__(64 * FE_WAVES)
-void k_frontend(const uint4 *__restrict__ iq,        // [total][480] uint4 (4 IQ samples each)
-                ChanState *__restrict__ st,
-                float *__restrict__ disc_raw,        // [total][384]
-                float *__restrict__ offs,            // [total]
-                int nblk, int total, int update_state)
-{
-    // per-wave double-buffered tile: [buf][row = lane's (channel,block)][20 samples]
-    __shared__ __attribute__((aligned(16))) uint32_t tile[FE_WAVES][2][64 * FE_STRIDE];
-    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    const int cb0 = ((int)blockIdx.x * FE_WAVES + wave) * 64;
-    if (cb0 >= total) return;                            // no block-level barrier below
-    const bool valid = (cb0 + lane) < total;
-    const int cb = valid ? cb0 + lane : total - 1;
-    const int chan = cb / nblk, blk = cb - chan * nblk;
-
-    // discriminator memory z[0], z[1] (m17_dsp.cpp:196): from channel state for
-    // the first block of the call, otherwise the limited last two samples of the
-    // preceding block, which sit right in front of this row in the IQ array.
-    // The state for the NEXT call -- the limited last two samples of the channel's last block -- is written by this
-    // same lane of block 0, behind its own read (fe_next_z): written by the lane of the last block, as it used to be,
-    // it could land before the block-0 lane of another wave had read the old one (workgroups of different XCDs run
-    // far apart in a large grid; seen as run-to-run differences above 65,536 channels).
-    float z0re, z0im, z1re, z1im;
-    float n0re = 0.0f, n0im = 0.0f, n1re = 0.0f, n1im = 0.0f;
-    if (blk == 0) {
-        z0re = st[chan].z0re; z0im = st[chan].z0im; z1re = st[chan].z1re; z1im = st[chan].z1im;
-        fe_next_z(iq, cb, nblk, n0re, n0im, n1re, n1im);
-    } else {
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(iq) + (size_t)cb * kBlockSamples;
-        const uint32_t a = p[-2], b = p[-1];
-        z1re = s16_to_float((int)(short)(a & 0xFFFF)); z1im = s16_to_float((int)a >> 16);
-        z0re = s16_to_float((int)(short)(b & 0xFFFF)); z0im = s16_to_float((int)b >> 16);
-        limit(z1re, z1im);
-        limit(z0re, z0im);
-    }
-
-    // staging slots of this lane: uint4 number (j*64+lane) of the chunk tile, i.e.
-    // 5 consecutive lanes fetch one row's 80-byte segment
-    uint4 stage[FE_LOADS];
-    const uint4 *gsrc[FE_LOADS];
-    int loff[FE_LOADS];
-#pragma unroll
-    for (int j = 0; j < FE_LOADS; ++j) {
-        const int idx = j * 64 + lane;
-        const int r = idx / FE_LOADS, c4 = idx - r * FE_LOADS;
-        int row = cb0 + r; row = row < total ? row : total - 1;
-        gsrc[j] = iq + (size_t)row * (kBlockSamples / 4) + c4;
-        loff[j] = r * FE_STRIDE + c4 * 4;
-    }
-#pragma unroll
-    for (int j = 0; j < FE_LOADS; ++j) stage[j] = gsrc[j][0];
-#pragma unroll
-    for (int j = 0; j < FE_LOADS; ++j) *reinterpret_cast<uint4 *>(&tile[wave][0][loff[j]]) = stage[j];
-    wave_lds_sync();
-
-    float offset = 0.0f;
-    float *dst = disc_raw + (size_t)cb * kDiscOut;
-    for (int chunk = 0; chunk < FE_NCHUNK; ++chunk) {
-        const uint32_t *cur = tile[wave][chunk & 1];
-        uint32_t *nxt = tile[wave][(chunk + 1) & 1];
-        // prefetch the next chunk (the last iteration re-reads its own chunk: no branch,
-        // the register array stays out of scratch)
-        const int nx = (chunk + 1 < FE_NCHUNK) ? chunk + 1 : chunk;
-#pragma unroll
-        for (int j = 0; j < FE_LOADS; ++j) stage[j] = gsrc[j][nx * FE_LOADS];
-        float o[FE_CHUNK / 5];
-#pragma unroll
-        for (int q = 0; q < FE_CHUNK / 4; ++q) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(&cur[lane * FE_STRIDE + q * 4]);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int s = q * 4 + e;
-                float re = s16_to_float((int)(short)(w[e] & 0xFFFF));
-                float im = s16_to_float((int)w[e] >> 16);
-                limit(re, im);
-                // dsp_arctan_disc2 (m17_dsp.cpp:194-222)
-                const float a = z0im * (re - z1re);
-                const float b = z0re * (im - z1im);
-                const float u = b - a;
-                z1re = z0re; z1im = z0im; z0re = re; z0im = im;
-                const float uh = u * 0.5f;
-                if (s % 5 == 4) o[s / 5] = uh;       // count%5==0 pick; 1920%5==0 keeps the phase
-                offset += uh;                         // strictly sequential DC sum
-            }
-        }
-        if (valid)
-            *reinterpret_cast<float4 *>(dst + chunk * (FE_CHUNK / 5)) = make_float4(o[0], o[1], o[2], o[3]);
-#pragma unroll
-        for (int j = 0; j < FE_LOADS; ++j) *reinterpret_cast<uint4 *>(&nxt[loff[j]]) = stage[j];
-        wave_lds_sync();
-    }
-    if (valid) {
-        offs[cb] = offset / (float)kBlockSamples;     // offset/len (m17_dsp.cpp:213)
-        if (update_state && blk == 0) {
-            st[chan].z0re = n0re; st[chan].z0im = n0im; st[chan].z1re = n1re; st[chan].z1im = n1im;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
-// k_frontend_q: the same stage with FOUR lanes per (channel, block), 16 per wave.
-// Used when there are too few channel-blocks to fill the chip with one lane each
-// (51,200 channel-blocks = 800 waves of k_frontend = 0.8 waves per SIMD).
+// k_frontend_q: the stage with FOUR lanes per (channel, block), 16 per wave (one lane per row, round 1's first kernel,
+// left 51,200 channel-blocks at 0.8 waves per SIMD and was slower at every size; removed in round 6).
 //   load   : the wave fetches a [16 rows][64 samples] tile with 16 lanes per row,
 //            i.e. 256 contiguous bytes per row per load instruction (measured:
 //            6.4 TB/s for this pattern vs 3.6 TB/s for 16-byte pieces), one chunk
@@ -353,7 +244,10 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
     float *myo = otile[wave];
 
     // z[0], z[1] at the start of the block, identical in the four lanes of a quad
-    // (the next call's state is written by the quad of block 0 itself, behind its read: see k_frontend)
+    // The state for the NEXT call -- the limited last two samples of the channel's last block -- is written by the quad of
+    // block 0 itself, behind its own read (fe_next_z): written by the lane of the last block it could land before the
+    // block-0 lane of another wave had read the old one (workgroups of different XCDs run far apart in a large grid;
+    // seen as run-to-run differences above 65,536 channels).
     float c0re, c0im, c1re, c1im;
     float n0re = 0.0f, n0im = 0.0f, n1re = 0.0f, n1im = 0.0f;
     if (blk == 0) {

@@ -135,6 +135,7 @@ struct WvCtl {
     uint32_t block_count;
     int nrec, sym_total;
     int hp;                                    // ring position of the block's first symbol
+    int work;                                  // timing rounds + framer passes of this call: what the channel cost (k_order, m17_fused.hip)
 #ifdef M17_STAMPS
     unsigned last_;
 #endif
@@ -170,6 +171,7 @@ __device__ __forceinline__ int wv_timing_block(WvCtl &t, const unsigned xb, cons
     while (t.clk == 1 && p < kDiscOut) tick();
     while (p < kDiscOut) {
         WCNT(8);
+        t.work++;
         WSTAMP(0);
         // Lane g takes the instant at input p + 2g.  Near the end of the block the upper lanes run past it: their
         // windows read what follows the block in the channel's LDS, and nothing of theirs is used -- no vote (okm),
@@ -251,6 +253,7 @@ __device__ __forceinline__ void wv_framer_block(WvCtl &t, WvOut &o, const int n,
     int pos = (o.ext_lock >= 0) ? n : 0;
     while (pos < n) {
         WCNT(10);
+        t.work++;
         if (t.flock) {
             const int cnt = min(kFrameSyms - t.fclk, n - pos);
             t.fclk += cnt; pos += cnt;
@@ -316,6 +319,7 @@ __device__ __forceinline__ void wv_load_state(WvCtl &t, const ChanState &cs, con
     t.nrec = (b0 == 0) ? 0 : uni(counts[chan]);
     t.sym_total = (b0 == 0) ? 0 : uni(cs.sym_total);
     t.hp = 256;
+    t.work = 0;
     if (t.flock) { for (int q = gl; q < t.fclk; q += 64) ring_st(t.hp - t.fclk + q, hb, cs.fsym[q]); }
     else if (gl < 8) ring_st(t.hp - 8 + gl, hb, cs.sync[gl]);
 }
@@ -340,8 +344,9 @@ __device__ __forceinline__ void wv_store_state(const WvCtl &t, ChanState &cs, in
 // OFFS_AGENT: the block offsets are read past the CU's caches (agent scope) -- for a caller whose rows were written in
 // this kernel by ANOTHER wave of the workgroup (k_rx_chan6's shared tiles): thirty-two offsets share a 128-byte line, and a
 // line this wave read for an earlier group must not be served again once a sibling has written the next group's part of it.
+// Returns the work the call took (WvCtl.work).
 template <int HALF = 0, int OFFS_AGENT = 0>
-__device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc, const float *__restrict__ offs,
+__device__ __forceinline__ int sync_wave_channel(const float *__restrict__ disc, const float *__restrict__ offs,
                        ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
                        m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
                        float *__restrict__ syms, int32_t *__restrict__ nsyms,
@@ -354,7 +359,7 @@ __device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc
     const unsigned long long rt_entry_ = __builtin_amdgcn_s_memrealtime();
 #endif
     const int gl = lane;
-    if (chan >= C) return;
+    if (chan >= C) return 0;
     const unsigned hb = (unsigned)uni((int)(unsigned)(uintptr_t)(lds_cfp)my.H);       // LDS byte address of the ring
     ChanState &cs = st[chan];
     if (!recs) rec_cap = 0;
@@ -454,6 +459,7 @@ __device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc
                                ((unsigned long long)((unsigned)__builtin_amdgcn_s_memtime() - t_entry_) << 32);
     }
 #endif
+    return t.work;
 }
 
 // Two builds of the kernel.  <0, 6>: the filter of a round as one statement with the branch's 62 tap registers and 16 window

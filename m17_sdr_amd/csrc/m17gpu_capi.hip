@@ -51,10 +51,11 @@ struct m17gpu_ctx {
     unsigned long long dst_override = 0;     // 48-bit destination callsign written into every net frame (0 = keep the LSF's)
     int afc = 0;                             // 1 = AFC on (radio_set_afc_on): block-sequential front end
     bool profiling = false;
-    int fe_impl = 0;                         // 0 = by size (four lanes per channel-block), 1 = lane per channel-block, 2 = four lanes,
-                                             // 3 = four lanes, DC chain and picks in registers (k_frontend_d: a third of the LDS traffic, same time)
+    int fe_impl = 0;                         // stand-alone front end: 0 | 2 = four lanes per channel-block, LDS chain (k_frontend_q, the default);
+                                             // 3 = the sixteen-row tile of k_sync_frame_duo<1> as a kernel (k_frontend_d: DC chain and picks in registers);
+                                             // 4 = the tile of k_rx_chan6 as a kernel (k_frontend_l: 32-sample chunks)
     int sync_impl = 0;                       // 0 | 6 = timing wave + framer wave per channel up to 1,024 channels, wave per channel beyond (default);
-                                             // 7 = wave per channel at every size
+                                             // 8 = wave per channel at every size
     int fe_debug = 0;                        // instrumented build only (scripts/exp_fe_bound.py)
     int book_impl = 0;                       // bookkeeping kernel: 0 = by batch (a lane per channel from 8,192 channels on, else a wave per channel), 1 = a wave
                                              // per channel (k_book_chan; always with the network sink attached), 2 = a lane per channel (k_book_lanes)
@@ -62,11 +63,19 @@ struct m17gpu_ctx {
                                              // 0 = by path: plain behind the wave-per-channel FIR stage, regrouped behind front end + timing kernel
     int32_t *d_flags = nullptr;              // [n_flags] verdict words of m17gpu_shard_gather_packed
     int n_flags = 0;
-    int fir_impl = 0;                        // 0 = by call (fir_choice); 1 = front end + timing kernel; 2 = the fused FIR-stage kernel (m17_fused.hip:
-                                             // measured 18 % slower at 16,384 x 12, kept under the parity tests); 3 = wave per channel
-                                             // over sixteen-row tiles of its own blocks, rows through the workspace (k_rx_chan);
-                                             // 4 = the same at six waves per SIMD (k_rx_chan6); 5 = three waves per channel, the front end
-                                             // one of them (k_sync_frame_duo<1>, up to 1,024 channels)
+    int fir_impl = 0;                        // 0 = by call (fir_choice); 1 = front end + timing kernel; 4 = wave per channel over sixteen-row
+                                             // tiles of its own blocks, rows through the workspace, six waves per SIMD (k_rx_chan6);
+                                             // 5 = three waves per channel, the front end one of them (k_sync_frame_duo<1>, up to 1,024 channels)
+    int order_impl = 0;                      // dispatch order of k_rx_chan6: 0 = by measurement (order_choice), 1 = channel order, 2 = by the cost of
+                                             // each channel's last call, heaviest first (k_order)
+    int split_impl = 0;                      // full-chain calls on the wave-per-channel stage: 0 = by measurement (split_choice), 1 = one part,
+                                             // 2..15 = the first split_impl / 16 of the channels as part A: its decoder and bookkeeping run on
+                                             // an internal stream beside the FIR stage of part B
+    hipStream_t s2 = nullptr;                // the internal stream (non-blocking, highest priority) and the events that fork it from and join it to the caller's
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int32_t *d_cost = nullptr, *d_perm = nullptr;   // [C] work of each channel's last k_rx_chan6 call / [C rounded up to 4] its dispatch order
+    bool nwork_dirty = false;                // a full-chain call got past k_worklist but not to the bookkeeping kernel that zeroes the counters
+    int last_path[4] = {0, 0, 0, 0};         // what the last m17gpu_rx_blocks call ran: FIR stage (fir_choice), plain slots, bookkeeping kernel, dispatch order
     std::vector<hipEvent_t> ev_pool;         // 7 events per profiled call: 5 stage marks + call start / end
     std::vector<int> ev_mode;                // mode of each profiled call
 };
@@ -180,21 +189,17 @@ int launch_frontend(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, float *disc,
     disc += (size_t)c0 * nblk * kDiscOut;
     offs += (size_t)c0 * nblk;
     ChanState *state = ctx->d_state + c0;
-    // measured on MI355X (scripts/exp_scale.py): the 4-lane kernel wins at 51,200 .. 196,608 channel-blocks,
-    // so it is the default at every size; fe_impl 1 keeps the one-lane kernel selectable
-    const bool quad = ctx->fe_impl != 1;
+    // four lanes per channel-block (k_frontend_q) at every size; 3 / 4 run the tiles of the fused kernels as kernels of
+    // their own (the lane-per-row kernel of round 1, fe_impl 1, was removed in round 6: slower at every size)
     if (ctx->fe_impl == 4)
         hipLaunchKernelGGL(k_frontend_l, dim3(cdiv(total, 16)), dim3(64), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state);
     else if (ctx->fe_impl == 3)
         hipLaunchKernelGGL(k_frontend_d, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state);
-    else if (quad)
+    else
         hipLaunchKernelGGL(k_frontend_q, dim3(cdiv(total, 16 * FQ_WAVES)), dim3(64 * FQ_WAVES), 0, st,
                            reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state | (ctx->fe_debug << 1));
-    else
-        hipLaunchKernelGGL(k_frontend, dim3(cdiv(total, 64 * FE_WAVES)), dim3(64 * FE_WAVES), 0, st,
-                           reinterpret_cast<const uint4 *>(d_iq), state, disc, offs, nblk, total, update_state);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -232,10 +237,9 @@ int launch_sync_frame(m17gpu_ctx *ctx, const float *disc, const float *offs, int
                            disc, offs, state, cn, nblk, mode, recs, recs ? rec_cap : 0,
                            counts, syms, nsyms, fsym, b0, bcount, nullptr, nullptr, nullptr);
     else {
-        // default (0 / 6 beyond 1,024 channels, and 8): taps and window through half the registers, eight waves per SIMD;
-        // 7 = round 3's form (all 62 tap registers, six waves per SIMD), 9 = the half-register form at six waves per SIMD
-        auto kern = ctx->sync_impl == 7 ? k_sync_frame_wave<0, 6> : ctx->sync_impl == 9 ? k_sync_frame_wave<1, 6> : k_sync_frame_wave<1, 8>;
-        hipLaunchKernelGGL(kern, dim3(cdiv(cn, WV_WAVES)), dim3(64 * WV_WAVES), 0, st,
+        // 0 / 6 beyond 1,024 channels, and 8: taps and window through half the registers, eight waves per SIMD (round 3's
+        // form with all 62 tap registers at six waves per SIMD, and the half-register form at six, were removed in round 6)
+        hipLaunchKernelGGL((k_sync_frame_wave<1, 8>), dim3(cdiv(cn, WV_WAVES)), dim3(64 * WV_WAVES), 0, st,
                            disc, offs, state, cn, nblk, kmode, ext_lock, recs, recs ? rec_cap : 0,
                            counts, syms, nsyms, fsym, b0, bcount);
     }
@@ -258,7 +262,7 @@ bool plain_slots(const m17gpu_ctx *ctx, int nblk)
     const int fir = fir_choice(ctx, nblk);
     if (fir == 5) return false;                     // the two-wave framer writes regrouped slots only
     if (ctx->slot_impl) return ctx->slot_impl == 1;
-    return fir == 3 || fir == 4;
+    return fir == 4;
 }
 // 5: front end, timing loop and framer of a channel on three waves of one workgroup (k_sync_frame_duo<1>) -- small
 // batches, where one channel per SIMD slot leaves both kernels latency-bound: up to 1,024 channels.  Short calls (under
@@ -271,7 +275,7 @@ int fir_choice(const m17gpu_ctx *ctx, int nblk)
     if (ctx->afc) return 1;
     const bool trio_ok = (ctx->sync_impl == 0 || ctx->sync_impl == 6) && ctx->C <= 1024 && ctx->slot_impl != 1;
     if (ctx->fir_impl == 5) return trio_ok ? 5 : 1;
-    if (ctx->fir_impl != 0) return ctx->fir_impl;
+    if (ctx->fir_impl != 0) return ctx->fir_impl;                   // 1 | 4
     if (trio_ok && (nblk < 16 || ctx->C >= 512)) return 5;
     // 4: the wave-per-channel stage works in tiles of sixteen of the channel's blocks; a last group of fewer blocks is packed
     // four channels to a workgroup's tiles (k_rx_chan6), so any call from twelve blocks on is served at the cost its rows
@@ -279,28 +283,45 @@ int fir_choice(const m17gpu_ctx *ctx, int nblk)
     // profiles/r05_channel_count_crossover.txt)
     return (ctx->C >= 10000 && nblk >= 12) ? 4 : 1;
 }
-int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
-                 int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st)
+// Measured (profiles/r06_dispatch_order_ab.txt): no gain -- the launch's tail is not made by the heavy channels coming last
+// (wave lifetimes differ by when a wave ran, not by what it had to do) -- and k_order costs ~8 us: off unless asked for.
+bool order_choice(const m17gpu_ctx *ctx)
 {
-    const int fir = fir_choice(ctx, nblk);
+    return ctx->order_impl == 2;
+}
+// Channels of part A of a split full-chain call (0 = no split).  k_rx_chan6 ends in a tail -- its last waves run alone on
+// their SIMDs, latency-bound -- and the decoder behind it is bound by the vector ALU: with the channels in two parts,
+// FIR(A), FIR(B) on the caller's stream and decoder + bookkeeping of A on an internal stream behind FIR(A), the decoder
+// of A runs beside FIR(B), whose 0.67 generation of waves leaves it room.
+int split_choice(const m17gpu_ctx *ctx, int nblk, int fir, bool full)
+{
+    if (!full || fir != 4 || ctx->split_impl == 1 || !ctx->s2) return 0;
+    const int k = ctx->split_impl ? ctx->split_impl : 0;
+    if (k == 0) return 0;
+    int a = (int)((long long)ctx->C * k / 16) & ~7;
+    return (a >= 8 && ctx->C - a >= 8) ? a : 0;
+}
+// the wave-per-channel FIR stage (k_rx_chan6) over the channel range [c0, c0 + cn)
+int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
+                 int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st, int c0 = 0, int cn = -1)
+{
+    if (cn < 0) cn = ctx->C;
     mode |= plain_slots(ctx, nblk) ? 16 : 0;                         // bit 4: plain frame slots
-    if (fir == 4) {
-        // the same built for six waves per SIMD (k_rx_chan6)
-        hipLaunchKernelGGL(k_rx_chan6, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
-                           reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->C, nblk, mode,
-                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
-                           d_syms, d_nsyms, ctx->d_fsym);
-    } else if (fir == 3)
-        // wave per channel, sixteen of its own blocks per front-end tile, rows handed over through the workspace (k_rx_chan)
-        hipLaunchKernelGGL(k_rx_chan, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
-                           reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->C, nblk, mode,
-                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
-                           d_syms, d_nsyms, ctx->d_fsym);
-    else
-        hipLaunchKernelGGL(k_rx_fused, dim3(cdiv(ctx->C, FU_WAVES)), dim3(64 * FU_WAVES), 0, st,
-                           reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->C, nblk, mode,
-                           reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
-                           d_syms, d_nsyms, ctx->d_fsym);
+    const int grid = cdiv(cn, RC_WAVES);
+    const bool order = order_choice(ctx);
+    int32_t *perm = ctx->d_perm + (c0 + 3) / 4 * 4, *cost = ctx->d_cost + c0;       // (ranges start on multiples of four)
+    if (order) {
+        // the range's channels by the work their last call took, heaviest first (channel numbers relative to the range)
+        hipLaunchKernelGGL(k_order, dim3(1), dim3(ORD_BINS), 0, st, cost, perm, cn, grid * RC_WAVES);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL((nblk % 16) ? k_rx_chan6<1> : k_rx_chan6<0>, dim3(grid), dim3(64 * RC_WAVES), 0, st,
+                       reinterpret_cast<const uint4 *>(d_iq) + (size_t)c0 * nblk * (kBlockSamples / 4), ctx->d_state + c0,
+                       ctx->d_disc + (size_t)c0 * nblk * kDiscOut, ctx->d_offs + (size_t)c0 * nblk, cn, nblk, mode,
+                       d_recs ? reinterpret_cast<m17gpu_rec_dev *>(d_recs) + (size_t)c0 * rec_cap : nullptr, d_recs ? rec_cap : 0,
+                       (d_counts ? d_counts : ctx->d_counts) + c0,
+                       d_syms ? d_syms + (size_t)c0 * M17_SYM_STRIDE(nblk) : nullptr, d_nsyms ? d_nsyms + (size_t)c0 * nblk : nullptr,
+                       ctx->d_fsym + (size_t)c0 * rec_cap * kSlotFloats, order ? perm : nullptr, cost);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -316,6 +337,7 @@ int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_c
     int32_t *work = ctx->d_work + 3 * (size_t)c0 * ctx->rec_cap_max;
     int32_t *nwork = ctx->d_nwork + 4 * chunk;
     const long long slots = (long long)cn * rec_cap;
+    ctx->nwork_dirty = true;                        // until the bookkeeping kernel, which zeroes the counters, is enqueued
     hipLaunchKernelGGL(k_worklist, dim3(cdiv(slots, 1024)), dim3(1024), 0, st, recs, rec_cap, cnt, cn,
                        work, nwork, (int)slots);
     // one launch for all three lists (k_decode_lists): stream frames, the bulk of any traffic, on five workgroups of
@@ -339,7 +361,9 @@ int launch_decode(m17gpu_ctx *ctx, m17gpu_rec *d_recs, int rec_cap, int32_t *d_c
     // kernel 19 us at 4,096 channels x 16 blocks, 28 at 8,192, 42 at 16,384, 80 at 32,768 -- unless the network sink is attached
     // (its frames are formatted by the wave-per-channel kernel); book_impl 1 / 2 force one
     // (its LDS holds four words of every record of its eight channels: calls of more than ~190 blocks stay with the wave kernel)
-    if (!ctx->d_net && (size_t)BL_CH * rec_cap * 16 <= 48 * 1024 && (ctx->book_impl == 2 || (ctx->book_impl == 0 && cn >= 8192)))
+    const bool lanes = !ctx->d_net && (size_t)BL_CH * rec_cap * 16 <= 48 * 1024 && (ctx->book_impl == 2 || (ctx->book_impl == 0 && cn >= 8192));
+    ctx->last_path[2] = lanes ? 2 : 1;
+    if (lanes)
         hipLaunchKernelGGL(k_book_lanes, dim3(cdiv(cn, BL_CH)), dim3(64), (size_t)BL_CH * rec_cap * 16, st, ctx->d_state + c0, recs, rec_cap, cnt, ctx->d_crc_basis, nwork, cn);
     else
     hipLaunchKernelGGL(k_book_chan, dim3(cn), dim3(64), 0, st, ctx->d_state + c0, recs, rec_cap, cnt, ctx->d_crc_basis,
@@ -389,10 +413,20 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     ALLOC(ctx->d_offs, sizeof(float) * cb);
     ALLOC(ctx->d_fsym, sizeof(float) * (size_t)n_channels * ctx->rec_cap_max * kSlotFloats);
     ALLOC(ctx->d_work, sizeof(int32_t) * 3 * (size_t)n_channels * ctx->rec_cap_max);   // one list per frame type (decode_impl 2)
-    ALLOC(ctx->d_nwork, sizeof(int32_t) * 4);
+    ALLOC(ctx->d_nwork, sizeof(int32_t) * 8);
+    ALLOC(ctx->d_cost, sizeof(int32_t) * (size_t)n_channels);
+    ALLOC(ctx->d_perm, sizeof(int32_t) * ((size_t)n_channels + 8));
     ALLOC(ctx->d_counts, sizeof(int32_t) * (size_t)n_channels);
     ALLOC(ctx->d_dec_hist, sizeof(uint32_t) * 32 * (size_t)n_channels);
 #undef ALLOC
+    {
+        int lo = 0, hi = 0;
+        hipError_t e_ = hipDeviceGetStreamPriorityRange(&lo, &hi);                  // (least, greatest): numerically hi <= lo
+        if (e_ == hipSuccess) e_ = hipStreamCreateWithPriority(&ctx->s2, hipStreamNonBlocking, hi);
+        if (e_ == hipSuccess) e_ = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+        if (e_ == hipSuccess) e_ = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+        if (e_ != hipSuccess) { m17gpu_destroy(ctx); return fail(M17GPU_ERR_HIP, std::string("m17gpu_create: internal stream: ") + hipGetErrorString(e_)); }
+    }
     rc = m17gpu_reset(ctx, nullptr);
     if (rc != M17GPU_OK) { m17gpu_destroy(ctx); return rc; }
     {
@@ -411,9 +445,13 @@ void m17gpu_destroy(m17gpu_ctx *ctx)
     if (!ctx) return;
     DeviceScope dev_scope_(ctx->device);
     void *bufs[] = {ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->d_fsym, ctx->d_work,
-                    ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis, ctx->d_dec_hist, ctx->d_flags};
+                    ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis, ctx->d_dec_hist, ctx->d_flags,
+                    ctx->d_cost, ctx->d_perm};
     for (void *p : bufs) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->s2) { (void)hipStreamSynchronize(ctx->s2); (void)hipStreamDestroy(ctx->s2); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
 }
 
@@ -425,7 +463,9 @@ int m17gpu_reset(m17gpu_ctx *ctx, void *stream)
     hipLaunchKernelGGL(k_reset, dim3(cdiv(words, 256)), dim3(256), 0, S(stream), ctx->d_state, ctx->C);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(ctx->d_dec_hist, 0, sizeof(uint32_t) * 32 * (size_t)ctx->C, S(stream)));
-    HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t) * 4, S(stream)));
+    HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t) * 8, S(stream)));
+    HIPCHK(hipMemsetAsync(ctx->d_cost, 0, sizeof(int32_t) * (size_t)ctx->C, S(stream)));      // no history: channel order
+    ctx->nwork_dirty = false;
     return M17GPU_OK;
 }
 
@@ -448,7 +488,17 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
     hipStream_t st = S(stream);
     int rc;
     const bool full = mode == 1;
-    // (the work-list counters are zero here: m17gpu_reset zeroed them, and every full-chain call leaves them zeroed -- k_book_chan)
+    // The work-list counters are zero here: m17gpu_reset zeroed them, and every full-chain call leaves them zeroed (the
+    // bookkeeping kernel, the last one of the call).  A call that returned between k_worklist and that kernel's launch
+    // did not: the next one zeroes them itself.  (All full-chain calls of a context are ordered on one stream: header.)
+    if (full) {
+        if (ctx->nwork_dirty) HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t) * 8, st));
+        ctx->nwork_dirty = false;
+    }
+    const int fir = fir_choice(ctx, nblk);
+    ctx->last_path[0] = fir; ctx->last_path[1] = plain_slots(ctx, nblk) ? 1 : 0; ctx->last_path[2] = 0;
+    ctx->last_path[3] = (fir == 4 && order_choice(ctx)) ? 1 : 0;
+    const int split_a = split_choice(ctx, nblk, fir, full);
     hipEvent_t *ev = nullptr;
     if (ctx->profiling && ctx->ev_mode.size() < 512) {
         const size_t base = ctx->ev_pool.size();
@@ -475,13 +525,18 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
             }
             MARK(1);
             MARK(2);
-        } else if (fir_choice(ctx, nblk) == 5) {
+        } else if (fir == 5) {
             MARK(1);                             // no separate front end: a third wave per channel, under the timing loop
             if ((rc = launch_sync_frame(ctx, ctx->d_disc, ctx->d_offs, nblk, mode, d_recs, rec_cap, d_counts,
                                         d_syms, d_nsyms, st, -1, 0, -1, 0, -1, d_iq)) != M17GPU_OK) return rc;
             MARK(2);
-        } else if (fir_choice(ctx, nblk) >= 2) {
-            MARK(1);                             // no separate front end: stage 0 reads as zero, stage 1 is the fused kernel
+        } else if (fir == 4) {
+            MARK(1);                             // no separate front end: stage 0 reads as zero, stage 1 is the wave-per-channel kernel
+            if (split_a) {
+                if ((rc = launch_fused(ctx, d_iq, nblk, mode, d_recs, rec_cap, d_counts, d_syms, d_nsyms, st, 0, split_a)) != M17GPU_OK) return rc;
+                HIPCHK(hipEventRecord(ctx->ev_fork, st));
+                if ((rc = launch_fused(ctx, d_iq, nblk, mode, d_recs, rec_cap, d_counts, d_syms, d_nsyms, st, split_a, ctx->C - split_a)) != M17GPU_OK) return rc;
+            } else
             if ((rc = launch_fused(ctx, d_iq, nblk, mode, d_recs, rec_cap, d_counts, d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
             MARK(2);
         } else {
@@ -491,8 +546,20 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
                                         d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
             MARK(2);
         }
-        if (full) {
+        if (full && split_a) {
+            // part A's decoder and bookkeeping on the internal stream, behind FIR(A) and beside FIR(B); part B's on the
+            // caller's stream, which then waits for the internal one: everything of the call is complete on `stream`
+            const bool plain = plain_slots(ctx, nblk);
+            HIPCHK(hipStreamWaitEvent(ctx->s2, ctx->ev_fork, 0));
+            if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, ctx->s2, 0, split_a, 0, nullptr, plain)) != M17GPU_OK) return rc;
+            HIPCHK(hipEventRecord(ctx->ev_join, ctx->s2));
+            if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, st, split_a, ctx->C - split_a, 1, ev ? ev[3] : nullptr, plain)) != M17GPU_OK) return rc;
+            HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+            ctx->nwork_dirty = false;
+            MARK(4);
+        } else if (full) {
             if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, st, 0, ctx->C, 0, ev ? ev[3] : nullptr, plain_slots(ctx, nblk))) != M17GPU_OK) return rc;
+            ctx->nwork_dirty = false;
             MARK(4);
         }
 #undef MARK
@@ -597,9 +664,11 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return fail(M17GPU_ERR_ARG, "m17gpu_set_option: bad argument");
     auto bad = [&]() { return fail(M17GPU_ERR_ARG, std::string("m17gpu_set_option: value out of range for ") + name); };
-    if (!std::strcmp(name, "sync_impl")) { if (value != 0 && (value < 6 || value > 9)) return bad(); ctx->sync_impl = value; }
-    else if (!std::strcmp(name, "fe_impl")) { if (value < 0 || value > 4) return bad(); ctx->fe_impl = value; }
-    else if (!std::strcmp(name, "fir_impl")) { if (value < 0 || value > 5) return bad(); ctx->fir_impl = value; }
+    if (!std::strcmp(name, "sync_impl")) { if (value != 0 && value != 6 && value != 8) return bad(); ctx->sync_impl = value; }
+    else if (!std::strcmp(name, "fe_impl")) { if (value != 0 && (value < 2 || value > 4)) return bad(); ctx->fe_impl = value; }
+    else if (!std::strcmp(name, "fir_impl")) { if (value != 0 && value != 1 && value != 4 && value != 5) return bad(); ctx->fir_impl = value; }
+    else if (!std::strcmp(name, "split_impl")) { if (value < 0 || value > 15) return bad(); ctx->split_impl = value; }
+    else if (!std::strcmp(name, "order_impl")) { if (value < 0 || value > 2) return bad(); ctx->order_impl = value; }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
     else if (!std::strcmp(name, "slot_impl")) { if (value < 0 || value > 2) return bad(); ctx->slot_impl = value; }
     else if (!std::strcmp(name, "book_impl")) { if (value < 0 || value > 2) return bad(); ctx->book_impl = value; }
@@ -1222,6 +1291,33 @@ int m17gpu_get_lock(m17gpu_ctx *ctx, uint8_t *h_lock)
     ON_CTX_DEVICE(ctx);
     std::vector<ChanState> h; int rc = fetch_state(ctx, h); if (rc) return rc;
     for (int c = 0; c < ctx->C; ++c) h_lock[c] = (uint8_t)(h[c].flock != 0);
+    return M17GPU_OK;
+}
+
+// m_clk, m_thr, m_index (m17_rx_sync.cpp:6-9), m_flock, m_fclk, m_frame_errors (m17_rx_frame.cpp:16-18) | the carried sum and
+// dif (m17_rx_sync.cpp:78), z[0] and z[1] of dsp_arctan_disc2 (m17_dsp.cpp:196) as re, im, and m_buff[1 .. 30], the timing
+// loop's delay line (m17_rx_sync.cpp:11; m_buff[0] leaves the window with the next input and is not kept)
+int m17gpu_get_timing_state(m17gpu_ctx *ctx, int32_t *h_int, float *h_flt)
+{
+    if (!ctx || !h_int || !h_flt) return fail(M17GPU_ERR_ARG, "m17gpu_get_timing_state: bad argument");
+    ON_CTX_DEVICE(ctx);
+    std::vector<ChanState> h; int rc = fetch_state(ctx, h); if (rc) return rc;
+    for (int c = 0; c < ctx->C; ++c) {
+        const ChanState &s = h[c];
+        int32_t *a = h_int + 6 * (size_t)c;
+        float *f = h_flt + 36 * (size_t)c;
+        a[0] = s.clk; a[1] = s.thr; a[2] = s.index; a[3] = s.flock; a[4] = s.fclk; a[5] = s.ferr;
+        f[0] = s.sum; f[1] = s.dif; f[2] = s.z0re; f[3] = s.z0im; f[4] = s.z1re; f[5] = s.z1im;
+        std::memcpy(f + 6, s.buff + 1, 30 * sizeof(float));
+    }
+    return M17GPU_OK;
+}
+
+// what the last m17gpu_rx_blocks call of the context ran (the library picks its kernels by call: DESIGN.md section 5)
+int m17gpu_get_last_path(const m17gpu_ctx *ctx, int h_path[4])
+{
+    if (!ctx || !h_path) return fail(M17GPU_ERR_ARG, "m17gpu_get_last_path: bad argument");
+    for (int i = 0; i < 4; ++i) h_path[i] = ctx->last_path[i];
     return M17GPU_OK;
 }
 

@@ -186,6 +186,45 @@ def test_stage_demap_and_frontend_match_oracle():
     rx.close()
 
 
+def test_libm_dependent_tables_on_this_box_equal_the_committed_fixtures():
+    """SURVEY H6's guard, on the box that runs the parity tests and the bench: the 2 x 40 x 31 polyphase tap tables are
+    computed at run time from the HOST's sin / cos / sqrt by the product (m17_tables.cpp:28-55) and by the oracle
+    (m17_oracle.c, m17_rx_sync_init m17_rx_sync.cpp:101-129) alike -- a libm that differed from the build container's would
+    move both sides together and every parity test would stay green.  The committed fixture (tests/golden/tables.npz) and
+    the four tap values SURVEY 8c recorded from the compiled reference do not move: product tables, oracle tables,
+    fixture and known answers must all agree here, bit for bit; the Golay tables (no libm) ride along."""
+    _torch()
+    import ctypes as C
+    import os
+    import m17_sdr_amd as m
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tables.npz"))
+    lib = m.lib()
+    mf = np.zeros((40, 31), np.float32)
+    md = np.zeros((40, 31), np.float32)
+    lib.m17gpu_get_taps(oracle.vp(mf), oracle.vp(md))
+    genc = np.zeros(4096, np.uint16)
+    gerr = np.zeros(4096, np.uint16)
+    lib.m17gpu_get_golay_tables(oracle.vp(genc), oracle.vp(gerr))
+    L = oracle.L()
+    omf = np.ctypeslib.as_array(L.m17o_tab_mf(), (40, 31))
+    omd = np.ctypeslib.as_array(L.m17o_tab_md(), (40, 31))
+    for name, a in (("product mf", mf), ("oracle mf", omf)):
+        np.testing.assert_array_equal(a.view(np.uint32), g["mf"].view(np.uint32), err_msg=name)
+    for name, a in (("product md", md), ("oracle md", omd)):
+        np.testing.assert_array_equal(a.view(np.uint32), g["md"].view(np.uint32), err_msg=name)
+    np.testing.assert_array_equal(genc, g["golay_enc"])
+    np.testing.assert_array_equal(gerr, g["golay_err"])
+    np.testing.assert_array_equal(np.ctypeslib.as_array(L.m17o_tab_golay_enc(), (4096,)), g["golay_enc"])
+    np.testing.assert_array_equal(np.ctypeslib.as_array(L.m17o_tab_golay_err(), (4096,)), g["golay_err"])
+    # the reference's own RRC design values (SURVEY 8c: build_rrc_filter(0.5, 1240, 80), m17_dsp.cpp:295-315)
+    f = (C.c_float * 1240)()
+    L.m17o_build_rrc_filter(f, C.c_float(0.5), 1240, 80)
+    np.testing.assert_array_equal(np.array([f[0], f[619], f[620], f[1239]], np.float32),
+                                  np.array([-4.53409848e-05, 0.0635405034, 0.0635166764, -5.35539584e-05], np.float32))
+    # and the tables the KERNELS read are the host tables: a receiver made here decodes a noiseless stream
+    # (test_full_chain_noiseless_delivers_payloads compares that with the oracle)
+
+
 def test_exact_arithmetic_selftest():
     """The shortened sqrt / reciprocal / int16-scale sequences must equal the literal
     IEEE / fp64 expressions on every input of their domains (exhaustive, on device)."""
@@ -197,7 +236,9 @@ def test_exact_arithmetic_selftest():
 
 
 @pytest.mark.parametrize("options", [
-    {"sync_impl": 6}, {"sync_impl": 7}, {"sync_impl": 8}, {"sync_impl": 9}, {"fe_impl": 1}, {"fe_impl": 2}, {"fe_impl": 3}, {"fe_impl": 4}, {"fir_impl": 1}, {"fir_impl": 2}, {"fir_impl": 3}, {"fir_impl": 4}, {"fir_impl": 5}, {"fir_impl": 5, "sync_impl": 6}, {"fir_impl": 1, "sync_impl": 7}, {"slot_impl": 1}, {"slot_impl": 2}, {"book_impl": 1}, {"book_impl": 2}, {"book_impl": 2, "fir_impl": 4}, {"slot_impl": 1, "fir_impl": 4}, {"slot_impl": 2, "fir_impl": 4}])
+    {"sync_impl": 8}, {"fe_impl": 3, "fir_impl": 1}, {"fe_impl": 4, "fir_impl": 1}, {"fir_impl": 1}, {"fir_impl": 4}, {"fir_impl": 4, "order_impl": 1},
+    {"fir_impl": 5}, {"fir_impl": 1, "sync_impl": 8}, {"slot_impl": 1}, {"slot_impl": 2}, {"book_impl": 1}, {"book_impl": 2},
+    {"book_impl": 2, "fir_impl": 4}, {"slot_impl": 2, "fir_impl": 4}])
 def test_every_kernel_variant_is_bit_exact(options):
     _rx_compare(C=40, nblk=22, mode=1, ebn0=200.0, nsf=12, options=options)
     _rx_compare(C=40, nblk=9, mode=1, ebn0=9.0, nsf=5, calls=3, options=options)
@@ -248,8 +289,8 @@ def test_config2_1024_channels_front_end_bit_exact():
     _rx_compare(C=1024, nblk=10, mode=0, ebn0=7.0, nsf=6)
 
 
-@pytest.mark.parametrize("ebn0,options,nblk", [(4.0, {}, 12), (8.0, {}, 12), (12.0, {}, 12), (10.0, {"fir_impl": 2}, 12), (10.0, {"fe_impl": 3}, 12),
-                                               (10.0, {"fir_impl": 3}, 12), (8.0, {}, 16), (200.0, {}, 16), (10.0, {"slot_impl": 2}, 16)])
+@pytest.mark.parametrize("ebn0,options,nblk", [(4.0, {}, 12), (8.0, {}, 12), (12.0, {}, 12), (10.0, {"fir_impl": 1}, 12), (10.0, {"fe_impl": 3, "fir_impl": 1}, 12),
+                                               (8.0, {}, 16), (200.0, {}, 16), (10.0, {"slot_impl": 2}, 16), (10.0, {"order_impl": 1}, 16)])
 def test_config4_16384_channels_awgn_bit_exact(ebn0, options, nblk):
     """BASELINE configs[3] at its real size: 16,384 channels on one GPU, band-limited AWGN, signal from
     the device generator (every channel distinct), DEFAULT options -- so the kernels the bench runs at this size
@@ -288,6 +329,95 @@ def test_config4_16384_channels_awgn_bit_exact(ebn0, options, nblk):
     parsed = int(((recs["flags"][valid] & m.F_PARSED) != 0).sum())
     assert parsed > (1000 if ebn0 >= 8.0 else 0), parsed
     rx.close()
+
+
+@pytest.mark.parametrize("C,nblk,ebn0", [(16384, 16, 200.0), (16384, 16, 8.0), (16384, 12, 10.0), (10240, 48, 9.0), (16384, 48, 200.0)])
+def test_fir_stage_at_the_size_the_roofline_figure_is_quoted_on(C, nblk, ebn0):
+    """The bench's `fir_stage_16384{,x12,x48}` legs -- the figures north_star's 40 % of HBM is held against -- run MODE 0 at
+    16,384 channels through the library's own kernel choice (asserted below: the wave-per-channel stage k_rx_chan6 -- whole
+    sixteen-block tiles at 16 and 48 blocks per call, the last group's tiles shared by a workgroup's four channels at 12,
+    three groups per channel at 48).  This is that configuration under the oracle, deterministically: the path
+    m17_dsp.cpp:461-476 -> m17_rx_sync.cpp:77-99 -> m17_rx_frame.cpp:126-177 without the parser -- every channel's
+    recovered symbols as uint32, symbol counts per block, framer records, lock and the whole timing / framer end state."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    rx = m.Receiver(C, nblk)
+    sig = rx.gen_batch(nblk, n_stream_frames=6, ebn0_db=ebn0, noise_cutoff_hz=6250.0 if ebn0 < 100.0 else 0.0)
+    out = rx.rx_blocks(sig["iq"], 0, rx.alloc_outputs(nblk, want_syms=True))
+    torch.cuda.synchronize()
+    assert rx.last_path()["fir"] == 4, rx.last_path()          # k_rx_chan6: the kernel the roofline figure belongs to
+    iq = sig["iq"].cpu().numpy()
+    del sig
+    och = oracle.Channels(C)
+    ref = och.rx_blocks(iq, mode=0, nthreads=16)
+    del iq
+    counts = out["counts"].cpu().numpy()
+    np.testing.assert_array_equal(counts, ref["counts"])
+    np.testing.assert_array_equal(out["nsyms"].cpu().numpy(), ref["nsyms"])
+    np.testing.assert_array_equal(out["syms"].cpu().numpy().view(np.uint32), ref["syms"].view(np.uint32))
+    recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
+    cap = recs.shape[1]
+    valid = np.arange(cap)[None, :] < counts[:, None]
+    g = recs.view(np.uint8).reshape(C, cap, 64)[valid]
+    r = ref["recs"].view(np.uint8).reshape(C, cap, 64)[valid]
+    bad = np.nonzero((g != r).any(axis=1))[0]
+    assert bad.size == 0, (bad[:5], g[bad[:1]], r[bad[:1]])
+    assert int(counts.sum()) > (C if ebn0 > 100.0 else C // 8)    # the framer did see frames (at 8 dB a quarter of the channels lock at all)
+    np.testing.assert_array_equal(rx.lock(), (och.field("m_flock") != 0).astype(np.uint8))
+    st = rx.timing_state()
+    for name in ("m_clk", "m_thr", "m_index", "m_fclk", "m_frame_errors"):
+        np.testing.assert_array_equal(st[name], och.field(name), err_msg=name)
+    for name in ("sum", "dif", "z"):
+        np.testing.assert_array_equal(st[name].view(np.uint32), np.ascontiguousarray(och.field(name)).view(np.uint32), err_msg=name)
+    # the delay line: m_buff[1 .. 30] (element 0 leaves the window with the next input; the library does not keep it)
+    np.testing.assert_array_equal(np.ascontiguousarray(st["m_buff"][:, 1:]).view(np.uint32),
+                                  np.ascontiguousarray(och.field("m_buff")[:, 1:]).view(np.uint32), err_msg="m_buff")
+    rx.close()
+
+
+def test_dispatch_order_is_a_permutation_and_changes_nothing():
+    """k_rx_chan6 serves its channels in the order k_order makes from the work each channel's last call took (heaviest
+    first).  Whatever that order is, every channel must be served exactly once and get the results
+    it gets in channel order: one stream in several calls (the order changes from call to call: channels lose and regain
+    lock at 9 dB) on a context with the order on and one with it off, both against the oracle; ragged channel count (the
+    last workgroup has three wave slots without a channel), calls of whole tiles and with a shared last group."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    C, lengths = 10001, (16, 16, 12, 32, 20)
+    total = sum(lengths)
+    gen = m.Receiver(C, total)
+    iq_all = gen.gen_batch(total, n_stream_frames=9, ebn0_db=9.0, noise_cutoff_hz=6250.0)["iq"]
+    gen.close()
+    iq_host = iq_all.cpu().numpy()
+    rxs = [m.Receiver(C, max(lengths)) for _ in range(2)]
+    for rx, o in zip(rxs, (2, 1)):
+        rx.set_option("fir_impl", 4)
+        rx.set_option("order_impl", o)
+    och = oracle.Channels(C)
+    at = 0
+    for nblk in lengths:
+        part = iq_all[:, at:at + nblk].contiguous()
+        ref = och.rx_blocks(np.ascontiguousarray(iq_host[:, at:at + nblk]), mode=1, nthreads=16, cap=rxs[0].rec_cap_max)
+        at += nblk
+        for rx, ordered in zip(rxs, (1, 0)):
+            out = rx.rx_blocks(part, 1, rx.alloc_outputs(nblk, want_syms=True))
+            torch.cuda.synchronize()
+            assert rx.last_path()["fir"] == 4 and rx.last_path()["ordered"] == ordered, rx.last_path()
+            counts = out["counts"].cpu().numpy()
+            np.testing.assert_array_equal(counts, ref["counts"])
+            np.testing.assert_array_equal(out["nsyms"].cpu().numpy(), ref["nsyms"])
+            np.testing.assert_array_equal(out["syms"].cpu().numpy().view(np.uint32), ref["syms"].view(np.uint32))
+            recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
+            cap = recs.shape[1]
+            valid = np.arange(cap)[None, :] < counts[:, None]
+            g = recs.view(np.uint8).reshape(C, cap, 64)[valid]
+            r = ref["recs"].view(np.uint8).reshape(C, cap, 64)[valid]
+            bad = np.nonzero((g != r).any(axis=1))[0]
+            assert bad.size == 0, (nblk, ordered, bad[:5], g[bad[:1]], r[bad[:1]])
+            np.testing.assert_array_equal(rx.lsf(), och.field("m_lsf"))
+            np.testing.assert_array_equal(rx.counters(), och.field("counters"))
+    for rx in rxs:
+        rx.close()
 
 
 def test_config5_total_channel_count_on_one_gpu_bit_exact():
@@ -546,10 +676,10 @@ def test_hostile_input_zero_saturated_and_noise():
     iq[9, :3] = 12345                                     # a constant carrier (symbols exactly 0.0: the hunt's zero filter), then the signal
     iq[10, 6:] = iq[10, 5, -1]                            # ... and the other way round
     _compare_raw(np.ascontiguousarray(iq), mode=1)
-    _compare_raw(np.ascontiguousarray(iq), mode=1, options={"sync_impl": 7})
-    _compare_raw(np.ascontiguousarray(iq), mode=0, options={"sync_impl": 7})
+    _compare_raw(np.ascontiguousarray(iq), mode=1, options={"sync_impl": 8})
+    _compare_raw(np.ascontiguousarray(iq), mode=0, options={"sync_impl": 8})
     # the front-end tiles of round 5 (halving at the picks, lane moves folded into the DC chain): zeros make NaNs there too
-    for opts in ({"fe_impl": 3}, {"fe_impl": 4}, {"fir_impl": 3}, {"fir_impl": 4}, {"fir_impl": 5}, {"fir_impl": 4, "slot_impl": 2}):
+    for opts in ({"fe_impl": 3, "fir_impl": 1}, {"fe_impl": 4, "fir_impl": 1}, {"fir_impl": 4}, {"fir_impl": 5}, {"fir_impl": 4, "slot_impl": 2}):
         _compare_raw(np.ascontiguousarray(iq), mode=1, options=opts)
     # ... and the four-row tiles of short calls (scalar conversion, chain through sixteen lanes)
     _compare_raw(np.ascontiguousarray(iq[:, :8]), mode=1, options={"fir_impl": 5})
@@ -566,7 +696,7 @@ def test_record_capacity_overflow_and_max_blocks():
     sig = m.generate_batch(6, 40, n_stream_frames=40, ebn0_db=200.0)
     counts, _ = _compare_raw(np.ascontiguousarray(sig["iq"][:, :20]), mode=0, rec_cap=5)
     assert counts.max() > 5
-    counts, _ = _compare_raw(np.ascontiguousarray(sig["iq"][:, :20]), mode=0, rec_cap=5, options={"sync_impl": 7})
+    counts, _ = _compare_raw(np.ascontiguousarray(sig["iq"][:, :20]), mode=0, rec_cap=5, options={"sync_impl": 8})
     assert counts.max() > 5
     # two calls with overflow in the first: framer / timing state must carry on exactly
     rx = m.Receiver(6, 20)
@@ -596,12 +726,17 @@ def test_set_option_rejects_unknown_and_out_of_range_values():
     _torch()
     import m17_sdr_amd as m
     rx = m.Receiver(2, 2)
-    for name, value in (("fe_impl", 101), ("fe_impl", 107), ("fe_impl", -1), ("fe_impl", 5), ("sync_impl", 2),
-                        ("sync_impl", 5), ("sync_impl", 1), ("sync_impl", 4), ("sync_impl", 10), ("fir_impl", 6), ("fir_impl", -1), ("slot_impl", 3), ("book_impl", 3), ("overlap_chunks", 2), ("fe_waves_per_cu", 8), ("lanes_per_channel", 16),
+    for name, value in (("fe_impl", 101), ("fe_impl", 107), ("fe_impl", -1), ("fe_impl", 5), ("fe_impl", 1), ("sync_impl", 2),
+                        ("sync_impl", 5), ("sync_impl", 1), ("sync_impl", 4), ("sync_impl", 10), ("sync_impl", 7), ("sync_impl", 9),
+                        ("fir_impl", 6), ("fir_impl", -1), ("fir_impl", 2), ("fir_impl", 3),         # removed in round 6: no longer reachable
+                        ("slot_impl", 3), ("book_impl", 3), ("order_impl", 3), ("order_impl", -1),
+                        ("overlap_chunks", 2), ("fe_waves_per_cu", 8), ("lanes_per_channel", 16),
                         ("decode_impl", 0), ("no_such_option", 1)):
         with pytest.raises(RuntimeError):
             rx.set_option(name, value)
-    for name, value in (("fe_impl", 0), ("fe_impl", 1), ("fe_impl", 2), ("fe_impl", 3), ("fe_impl", 4), ("sync_impl", 0), ("sync_impl", 6), ("sync_impl", 7), ("sync_impl", 8), ("sync_impl", 9), ("fir_impl", 0), ("fir_impl", 1), ("fir_impl", 2), ("fir_impl", 3), ("fir_impl", 4), ("fir_impl", 5), ("slot_impl", 1), ("slot_impl", 2), ("slot_impl", 0), ("book_impl", 1), ("book_impl", 2), ("book_impl", 0)):
+    for name, value in (("fe_impl", 0), ("fe_impl", 2), ("fe_impl", 3), ("fe_impl", 4), ("sync_impl", 0), ("sync_impl", 6), ("sync_impl", 8),
+                        ("fir_impl", 0), ("fir_impl", 1), ("fir_impl", 4), ("fir_impl", 5), ("slot_impl", 1), ("slot_impl", 2), ("slot_impl", 0),
+                        ("book_impl", 1), ("book_impl", 2), ("book_impl", 0), ("order_impl", 1), ("order_impl", 2), ("order_impl", 0)):
         rx.set_option(name, value)
     rx.close()
 
@@ -821,7 +956,7 @@ def test_stage_decode_frames_mixed_types_and_golay():
     rx.close()
 
 
-@pytest.mark.parametrize("sync_impl", [0, 7])
+@pytest.mark.parametrize("sync_impl", [0, 8])
 def test_afc_loop_tolerance_parity_on_frequency_offsets(sync_impl):
     """the AFC branch (dsp_nco_mixer m17_dsp.cpp:390-408,468; radio_afc /
     radio_get_afc_delta radio.cpp:196-208), off by default in the reference and here.  Channels with carrier
@@ -1030,6 +1165,88 @@ def test_a_call_can_be_captured_in_a_hip_graph_and_replayed():
         assert torch.equal(a[1], b[1])
         assert torch.equal(a[0], b[0])
         assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
+
+
+@pytest.mark.parametrize("C,split", [(10240, 12), (10003, 8), (16384, 13)])
+def test_split_calls_are_complete_on_the_callers_stream_and_bit_exact(C, split):
+    """split_impl: a full-chain call on the wave-per-channel stage processes its channels in two parts -- FIR(A), FIR(B) on
+    the caller's stream, decoder + bookkeeping of A on the context's internal stream beside FIR(B) -- and joins the
+    internal stream before it returns the caller's.  Consecutive calls without any host synchronisation between them, the
+    outputs copied on the caller's stream right behind each call: every call against the oracle (a decoder of A that the
+    caller's stream did not wait for, or work-list counters shared by the two parts, would show here).  Also captured in
+    a HIP graph and replayed (the fork / join through events is a capturable pattern)."""
+    torch = _torch()
+    import m17_sdr_amd as m
+    lengths = (16, 16, 20, 16)
+    total = sum(lengths)
+    gen = m.Receiver(C, total)
+    iq_all = gen.gen_batch(total, n_stream_frames=9, ebn0_db=11.0, noise_cutoff_hz=6250.0)["iq"]
+    gen.close()
+    iq_host = iq_all.cpu().numpy()
+    rx = m.Receiver(C, max(lengths))
+    rx.set_option("fir_impl", 4)
+    rx.set_option("split_impl", split)
+    s = torch.cuda.Stream()
+    got = []
+    at = 0
+    with torch.cuda.stream(s):
+        for nblk in lengths:
+            part = iq_all[:, at:at + nblk].contiguous()
+            at += nblk
+            out = rx.rx_blocks(part, 1, rx.alloc_outputs(nblk, want_syms=True))
+            got.append({k: out[k].clone() for k in ("recs", "counts", "syms", "nsyms")})      # on s, behind the call: no host sync
+    torch.cuda.synchronize()
+    och = oracle.Channels(C)
+    at = 0
+    for nblk, out in zip(lengths, got):
+        ref = och.rx_blocks(np.ascontiguousarray(iq_host[:, at:at + nblk]), mode=1, nthreads=16, cap=rx.rec_cap_max)
+        at += nblk
+        counts = out["counts"].cpu().numpy()
+        np.testing.assert_array_equal(counts, ref["counts"])
+        np.testing.assert_array_equal(out["nsyms"].cpu().numpy(), ref["nsyms"])
+        np.testing.assert_array_equal(out["syms"].cpu().numpy().view(np.uint32), ref["syms"].view(np.uint32))
+        recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
+        cap = recs.shape[1]
+        valid = np.arange(cap)[None, :] < counts[:, None]
+        g = recs.view(np.uint8).reshape(C, cap, 64)[valid]
+        r = ref["recs"].view(np.uint8).reshape(C, cap, 64)[valid]
+        bad = np.nonzero((g != r).any(axis=1))[0]
+        assert bad.size == 0, (nblk, bad[:5], g[bad[:1]], r[bad[:1]])
+    np.testing.assert_array_equal(rx.lsf(), och.field("m_lsf"))
+    np.testing.assert_array_equal(rx.counters(), och.field("counters"))
+    # ... and as a captured graph: replay on the next 16 blocks of a second stream of blocks against plain calls
+    if C == 10240:
+        slabs = [iq_all[:, 16 * k:16 * (k + 1)].contiguous() for k in range(3)]
+
+        def run(graph):
+            r2 = m.Receiver(C, 16)
+            r2.set_option("fir_impl", 4)
+            r2.set_option("split_impl", split)
+            out = r2.alloc_outputs(16)
+            stage = torch.empty_like(slabs[0])
+            res = []
+            s2 = torch.cuda.Stream()
+            with torch.cuda.stream(s2):
+                stage.copy_(slabs[0]); r2.rx_blocks(stage, 1, out)
+                torch.cuda.synchronize()
+                g = None
+                if graph:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s2):
+                        r2.rx_blocks(stage, 1, out)
+                for k in range(1, 3):
+                    stage.copy_(slabs[k])
+                    if g is not None:
+                        g.replay()
+                    else:
+                        r2.rx_blocks(stage, 1, out)
+                    torch.cuda.synchronize()
+                    res.append((out["recs"].clone(), out["counts"].clone()))
+            r2.close()
+            return res
+        for a, b in zip(run(False), run(True)):
+            assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+    rx.close()
 
 
 def test_squelched_channels_do_not_slow_the_timing_stage():
