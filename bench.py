@@ -42,6 +42,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_FRONT = 7680 + 768              # IQ in + symbols out per channel-block
 BYTES_FULL = 7680 + 64                # IQ in + 64-byte record out
 KNAMES = ["k_frontend", "k_sync_frame", "k_worklist+k_decode", "k_bookkeeping"]
+EXIT_FANOUT_ABANDONED = 3             # the watchdog ended hung transfer legs: the line was printed WITHOUT them (a crash is 1, a signal > 128)
 
 
 def parse_args(argv=None):
@@ -122,10 +123,20 @@ def launch_ranks(args, timeout_s=1200.0):
                          else f"bench.py: ranks still running after {timeout_s:.0f} s were stopped\n")
     out0.seek(0)
     text = out0.read()
-    if bad or any(p.returncode for p in procs):
-        sys.stdout.write(text)
-        return (bad[1] if bad else 1) or 1
     line = [ln for ln in text.splitlines() if ln.startswith("{")]
+    rcs = [p.returncode for p in procs]
+    if bad or any(rcs):
+        # the line, if rank 0 got as far as printing it (the watchdog prints it before it ends the ranks), survives whatever
+        # the ranks' exit codes are; the code says what happened: EXIT_FANOUT_ABANDONED when every failing rank ended
+        # that way (the compute-only measurement is whole, the transfer legs are not), else the first failure's
+        if line:
+            print(line[-1], flush=True)
+        else:
+            sys.stdout.write(text)
+        failing = [rc for rc in rcs if rc not in (0, None)]
+        if failing and all(rc == EXIT_FANOUT_ABANDONED for rc in failing):
+            return EXIT_FANOUT_ABANDONED
+        return (bad[1] if bad else 1) or 1
     if not line:
         sys.stderr.write("bench.py: rank 0 printed no result line\n")
         return 1
@@ -276,24 +287,34 @@ def load_traffic(key):
         return None, None
 
 
-def roofline_obj(kms, ncalls, mode, cb_per_launch, key):
+def roofline_obj(kms, ncalls, mode, cb_per_launch, key, path=None, wall_ms=None):
+    """path = Receiver.last_path() of the timed calls: which kernels ran is what the library says it ran, not a guess from
+    the durations.  wall_ms = the step by the wall clock of the same launches: `frac_wall` is what a caller gets,
+    `frac` what the kernels take by HIP events between them."""
     per_unit = BYTES_FRONT if mode == 0 else BYTES_FULL
     kms = list(kms)
     names = list(KNAMES)
-    if 0.0 < kms[0] < 0.05 * kms[1]:
-        # the wave-per-channel FIR stage ran (whole sixteen-block tiles at >= 10,000 channels: k_rx_chan6 = front end, timing loop
-        # and framer of a channel in one wave): there is no front-end launch, the first interval is the gap between two events
+    fir = (path or {}).get("fir", 1)
+    if fir in (4, 5):
+        # one kernel for front end, timing loop and framer of a channel: k_rx_chan6 (a wave per channel) or, up to 1,024
+        # channels, k_sync_frame_duo<1> (three waves per channel); there is no front-end launch, the first interval is
+        # the gap between two events
         kms[1] += kms[0]
         kms[0] = 0.0
-        # ... or, up to 1,024 channels, front end, timing loop and framer of a channel on three waves of one workgroup
-        names[1] = "k_rx_chan6" if int(key.split(":")[1].split("x")[0]) > 1024 else "k_sync_frame_duo<1>"
+        names[1] = "k_rx_chan6" if fir == 4 else "k_sync_frame_duo<1>"
+    if path:
+        names[3] = {1: "k_book_chan", 2: "k_book_lanes"}.get(path.get("book"), names[3])
+        if path.get("plain_slots"):
+            names[2] = "k_worklist+k_decode_lists_p"
     used = [i for i in range(4) if kms[i] > 0.002]
     t_path_ms = sum(kms[i] for i in used)
     dom = max(used, key=lambda i: kms[i]) if used else 0
     achieved = per_unit * cb_per_launch / (t_path_ms * 1e-3) / 1e9 if t_path_ms > 0 else 0.0
     traffic, tsrc = load_traffic(key)
+    frac_wall = round(per_unit * cb_per_launch / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if wall_ms else None
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_wall": frac_wall, "wall_ms": round(wall_ms, 4) if wall_ms else None,
+            "traffic": traffic, "traffic_source": tsrc, "path": path,
             "kernel": "+".join(names[i] for i in used), "dominant": names[dom],
             "algorithmic_bytes_per_channel_block": per_unit, "channel_blocks_per_launch": cb_per_launch,
             "avg_ms": {names[i]: round(kms[i], 4) for i in used}, "kernel_sum_ms": round(t_path_ms, 4),
@@ -329,17 +350,18 @@ def fir_stage(args, torch, device, C=1024, nblk=50, steps=30, warm=3):
     dt = time.perf_counter() - t0
     rx.set_profiling(False)
     kms, ncalls = rx.kernel_ms()
+    path = rx.last_path()
     rx.close()
     del slabs
     torch.cuda.empty_cache()
-    ro = roofline_obj(kms, ncalls, 0, C * nblk, f"frontend:{C}x{nblk}")
+    ro = roofline_obj(kms, ncalls, 0, C * nblk, f"frontend:{C}x{nblk}", path, dt / steps * 1e3)
     what = "BASELINE configs[1]" if (C, nblk) == (1024, 50) else "the FIR stage at the headline's per-GPU batch"
     return {"workload": f"{what}: {C:,} channels x {nblk} blocks per launch ({nblk * 40} ms of signal buffered per call), "
                         "RRC FIR + timing recovery + sync correlator only",
             "blocks_per_launch": nblk,
             "ms": round(dt / steps * 1e3, 4), "value": round(C * nblk * 192 * steps / dt / 1e6, 3), "unit": "Msym/s",
-            "frac": ro["frac"], "achieved": ro["achieved"], "traffic": ro["traffic"], "avg_ms": ro["avg_ms"],
-            "kernel_sum_ms": ro["kernel_sum_ms"], "algorithmic_bytes_per_channel_block": BYTES_FRONT,
+            "frac": ro["frac"], "frac_wall": ro["frac_wall"], "achieved": ro["achieved"], "traffic": ro["traffic"], "avg_ms": ro["avg_ms"],
+            "kernel_sum_ms": ro["kernel_sum_ms"], "path": path, "algorithmic_bytes_per_channel_block": BYTES_FRONT,
             "channel_blocks_per_launch": C * nblk, "steps": steps, "warmup": warm, "settle_calls": settled, "target_frac": 0.40}
 
 
@@ -372,15 +394,16 @@ def noisy_leg(args, torch, device, C, nblk, ebn0=8.0):
     dt = time.perf_counter() - t0
     rx.set_profiling(False)
     kms, ncalls = rx.kernel_ms()
+    path = rx.last_path()
     locked = int(rx.lock().sum())
     rx.close()
     del slabs
     torch.cuda.empty_cache()
-    ro = roofline_obj(kms, ncalls, 1, C * nblk, f"full-noisy:{C}x{nblk}")
+    ro = roofline_obj(kms, ncalls, 1, C * nblk, f"full-noisy:{C}x{nblk}", path, dt / steps * 1e3)
     return {"workload": f"full chain, {C:,} channels x {nblk} blocks per step, band-limited AWGN at Eb/N0 {ebn0:g} dB (BASELINE configs[3])",
             "ebn0_db": ebn0, "ms": round(dt / steps * 1e3, 4), "value": round(C * nblk * 192 * steps / dt / 1e6, 3),
-            "unit": "Msym/s", "frac": ro["frac"], "achieved": ro["achieved"], "traffic": ro["traffic"], "avg_ms": ro["avg_ms"],
-            "kernel_sum_ms": ro["kernel_sum_ms"], "steps": steps, "warmup": warm, "settle_calls": settled,
+            "unit": "Msym/s", "frac": ro["frac"], "frac_wall": ro["frac_wall"], "achieved": ro["achieved"], "traffic": ro["traffic"], "avg_ms": ro["avg_ms"],
+            "kernel_sum_ms": ro["kernel_sum_ms"], "path": path, "steps": steps, "warmup": warm, "settle_calls": settled,
             "channels_locked_at_end": locked}
 
 
@@ -414,14 +437,29 @@ def step12_leg(args, torch, device, C, nblk=12):
     dt = time.perf_counter() - t0
     rx.set_profiling(False)
     kms, ncalls = rx.kernel_ms()
+    path = rx.last_path()
     rx.close()
     del slabs
     torch.cuda.empty_cache()
-    ro = roofline_obj(kms, ncalls, 1, C * nblk, f"full:{C}x{nblk}")
+    ro = roofline_obj(kms, ncalls, 1, C * nblk, f"full:{C}x{nblk}", path, dt / steps * 1e3)
     return {"workload": f"full chain, {C:,} channels x {nblk} blocks per step ({nblk * 40} ms of signal), noiseless: the default step of rounds 1-4",
             "ms": round(dt / steps * 1e3, 4), "value": round(C * nblk * 192 * steps / dt / 1e6, 3), "unit": "Msym/s",
-            "frac": ro["frac"], "achieved": ro["achieved"], "traffic": ro["traffic"], "avg_ms": ro["avg_ms"],
-            "kernel_sum_ms": ro["kernel_sum_ms"], "steps": steps, "warmup": warm, "settle_calls": settled}
+            "frac": ro["frac"], "frac_wall": ro["frac_wall"], "achieved": ro["achieved"], "traffic": ro["traffic"], "avg_ms": ro["avg_ms"],
+            "kernel_sum_ms": ro["kernel_sum_ms"], "path": path, "steps": steps, "warmup": warm, "settle_calls": settled}
+
+
+def pci_bus_id(torch, device):
+    """PCI bus id of the HIP device (domain:bus:device.function), through the runtime torch runs on."""
+    import ctypes as C
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        buf = C.create_string_buffer(32)
+        if hip.hipDeviceGetPCIBusId(buf, 32, int(device)) == 0:
+            return buf.value.decode()
+    except OSError:
+        pass
+    p = torch.cuda.get_device_properties(device)
+    return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
 
 
 def host_cores():
@@ -478,6 +516,12 @@ class CapiFanout:
         self.rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, self.UID, C.c_int]
         if self.rccl.ncclCommInitRank(C.byref(self.comm), self.world, self.uid, self.rank) != 0:
             raise RuntimeError("ncclCommInitRank failed")
+        n, d = C.c_int(-1), C.c_int(-1)
+        self.rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self.rccl.ncclCommCuDevice.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        if self.rccl.ncclCommCount(self.comm, C.byref(n)) != 0 or self.rccl.ncclCommCuDevice(self.comm, C.byref(d)) != 0:
+            raise RuntimeError("ncclCommCount / ncclCommCuDevice failed")
+        self.count, self.cu_device = n.value, d.value       # RCCL's own view: ranks in the communicator, this rank's device
 
     def _chk(self, rc, what):
         if rc != 0:
@@ -635,6 +679,7 @@ def fanout_legs(args, torch, dist, rx, out, iq_step, world, rank, backend, C, nb
     if world > 1:
         dist.all_reduce(vals, op=dist.ReduceOp.MAX)
     sc, cp, ga, ov = (float(v) * 1e3 for v in vals.tolist())
+    capi_count = (capi.count, capi.cu_device) if capi else (None, None)
     if capi:
         capi.close()
     rec_bytes = rec_rows[0] * 64 + (C + 1) * 4
@@ -643,7 +688,7 @@ def fanout_legs(args, torch, dist, rx, out, iq_step, world, rank, backend, C, nb
             "iq_bytes_per_peer": C * nblk * 7680, "records_bytes_per_rank": rec_bytes,
             "records_bytes_unpacked": int(out["recs"].numel()) + 4 * C,
             "scatter_GBps_from_root": round((world - 1) * C * nblk * 7680 / (sc * 1e-3) / 1e9, 2) if world > 1 and sc > 0 else None,
-            "reps": reps,
+            "reps": reps, "ncclCommCount": capi_count[0], "ncclCommCuDevice": capi_count[1],
             "transport": ("C-ABI m17gpu_shard_scatter_iq / m17gpu_pack_records / m17gpu_shard_gather_packed on an ncclComm_t (RCCL)" if capi
                           else "m17_sdr_amd.shard over torch.distributed: RCCL point-to-point" if backend == "nccl"
                           else f"m17_sdr_amd.shard over torch.distributed: {backend} (rehearsal, staged through host)")}
@@ -702,11 +747,21 @@ def run_rank(args):
     dt = time.perf_counter() - t0
     rx.set_profiling(False)
     kms, ncalls = rx.kernel_ms()
+    path = rx.last_path()
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # who took part, as each rank sees itself: its device (PCI bus id) and the channel range it owns -- the day a
+    # scaling run happens, "did N ranks on N different GPUs each process their shard" is answerable from the line
+    me = {"rank": rank, "local_rank": local, "host": socket.gethostname(), "device": local, "pci_bus_id": pci_bus_id(torch, local),
+          "shard_range": list(m.shard.channel_range(rank, world, world * C)), "channels": C}
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+    else:
+        ranks = [me]
 
     syms = world * C * nblk * 192 * args.steps
     msym = syms / dt / 1e6
@@ -732,7 +787,15 @@ def run_rank(args):
                                      if args.gen == "gpu" else "m17gen_batch (host, tiled), the same slab every step"),
                    "parallelism": f"channel-sharded x{world}, one process per GPU, no data-path collective in the timed region"},
         "roofline": roofline_obj(kms, ncalls, mode, C * nblk,
-                                 f"{args.workload}{'-noisy' if (args.ebn0 < 100.0 and args.noise_cutoff > 0) else ''}:{C}x{nblk}"),
+                                 f"{args.workload}{'-noisy' if (args.ebn0 < 100.0 and args.noise_cutoff > 0) else ''}:{C}x{nblk}",
+                                 path, ms_step),
+        "ranks": ranks,
+        "collectives": {"backend": ("RCCL (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
+                        "world_size": dist.get_world_size() if world > 1 else 1,
+                        "distinct_devices": len({(r["host"], r["pci_bus_id"]) for r in ranks}),
+                        "ncclCommCount": None,
+                        "note": "ncclCommCount = RCCL's own count of the ranks in the communicator the C-ABI fan-out legs run on "
+                                "(filled in by those legs: N > 1, or --fanout capi at N = 1); world_size = torch.distributed's"},
     }
     if args.option:
         line["config"]["options"] = list(args.option)
@@ -754,7 +817,7 @@ def run_rank(args):
                 line["cpu_baseline"] = None
                 sys.stdout.write(json.dumps(line) + "\n")
                 sys.stdout.flush()
-            os._exit(0)
+            os._exit(EXIT_FANOUT_ABANDONED)     # not 0: the legs are missing from the line; not a crash either
 
         for ti, tr in enumerate(transports):
             key = "fanout" if ti == 0 else f"fanout_{tr}"
@@ -769,6 +832,8 @@ def run_rank(args):
                 fan = {"fanout_error": f"{type(e).__name__}: {e}"[:300]}
             dog.cancel()
             line[key] = fan
+            if fan.get("ncclCommCount") is not None:
+                line["collectives"]["ncclCommCount"] = fan["ncclCommCount"]
             sfx = "" if ti == 0 else f"_{tr}"
             if "fanout_ms" in fan:
                 wf = ms_step + fan["fanout_ms"] + fan["gather_ms"]

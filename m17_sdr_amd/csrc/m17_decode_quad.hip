@@ -79,7 +79,7 @@ __device__ __forceinline__ float dq_symbol(const float *gs, uint32_t e)
 __device__ __forceinline__ float dq_soft(uint32_t e, float symval, float ncor)
 {
     const float nm = symval * ncor;
-    const float odd = (float)((double)fabsf(nm) - 0.6666);
+    const float odd = (float)((double)fabsf(nm) - M17_LIT_DEMAP_OFFSET);
     const uint32_t pm = (uint32_t)__builtin_amdgcn_sbfe((int)e, 10, 1);              // all ones: second bit of the dibit
     uint32_t v = (pm & __float_as_uint(odd)) | (~pm & __float_as_uint(nm));
     v ^= e & 0x80000000u;
@@ -94,6 +94,8 @@ __device__ __forceinline__ float dq_soft(uint32_t e, float symval, float ncor)
 __host__ __device__ inline DqLich dq_lich_entry(int g)       // e: offset, bit 10 and bit 31 as above
 {
     // 0.6666 lies strictly between the floats 0x3F2AA64C (0.66659999) and 0x3F2AA64D (0.66660005)
+    static_assert((double)__builtin_bit_cast(float, 0x3F2AA64Cu) < M17_LIT_DEMAP_OFFSET && M17_LIT_DEMAP_OFFSET < (double)__builtin_bit_cast(float, 0x3F2AA64Du),
+                  "the LICH thresholds are the two floats around the demapper's offset");
     DqLich L;
     L.e = dq_entry(g);
     const bool second = (L.e >> 10) & 1u, neg = (L.e >> 31) != 0u;
@@ -233,7 +235,7 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW, NSYM> &F, cons
         float sum = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) sum += fabsf(s8[i]);
-        ncor = -(8.0f / sum);                  // cor = (float)(8.0/(double)sum), see limit()
+        ncor = -((float)M17_LIT_DEMAP_COR_NUM / sum);      // cor = (float)(8.0/(double)sum), see limit()
     }
     // ---- LICH (m17_rx_parse.cpp:118-135): quad lane j decodes Golay word j
     uint32_t gdata = 0, gpar = 0, genc_v = 0, gerr_v = 0;
@@ -254,7 +256,7 @@ __device__ __forceinline__ void decode_quad_pass(QuadFrameT<DECW, NSYM> &F, cons
 
     // ---- forward pass (m17_viterbi_decode, m17_conv.cpp:148-158)
     // path metrics of states 4j .. 4j+3: two register sets, a trellis step reads one and writes the other
-    float A0 = (j == 0) ? 1.0f : 0.0f, A1 = 0.0f, A2 = 0.0f, A3 = 0.0f, B0, B1, B2, B3;     // :150-153
+    float A0 = (j == 0) ? M17_LIT_ACM0 : 0.0f, A1 = 0.0f, A2 = 0.0f, A3 = 0.0f, B0, B1, B2, B3;     // :150-153
     uint32_t dw = 0;
     // One add-compare-select (BF, m17_conv.cpp:19): ta = acm[even predecessor] + M, tb = acm[odd predecessor] - M with
     // the predecessors' metrics arriving as DPP operands of the adds (old states 2v, 2v+1 mod 16 sit in quad lane

@@ -20,6 +20,44 @@ constexpr int kSoftBits     = 368;
 constexpr int kPhases       = 40;     // m17_rx_sync.cpp:3
 constexpr int kTaps         = 31;     // m17_rx_sync.cpp:4
 
+// The literals and control constants of the reference's streaming arithmetic, each under ONE name: the kernels and the
+// host tables use these names where the reference has the literal, and m17gpu_get_constant("rx_literals") returns them in
+// this order -- tests/test_ref_constants.py holds that array against the values tests/golden/extract_ref_constants.py
+// found in the reference's source text (and against the oracle's own), so a mistyped threshold cannot hide.
+#define M17_LIT_S16_SCALE           0.00003   /* m17_dsp.cpp:138-139  out = in * 0.00003 (double) */
+#define M17_LIT_DEMAP_OFFSET        0.6666    /* m17_dsp.cpp:41       fabs(m) - 0.6666 (double) */
+#define M17_LIT_DEMAP_COR_NUM       8.0       /* m17_dsp.cpp:88       cor = 8.0 / sum (double) */
+#define M17_LIT_DEMAP_SYNC_SYMBOLS  8         /* m17_dsp.cpp:85       sum over the 8 sync symbols */
+#define M17_LIT_DISC_C              0.5f      /* m17_dsp.cpp:199      u * c */
+#define M17_LIT_DISC_DECIM          5         /* m17_dsp.cpp:207      count = (count + 1) % 5 */
+#define M17_LIT_LIMIT_NUM           1.0       /* m17_dsp.cpp:415      g = 1.0 / m (double) */
+#define M17_LIT_THRESH_UNLOCKED     10        /* m17_rx_sync.cpp:93 */
+#define M17_LIT_THRESH_LOCKED       80        /* m17_rx_sync.cpp:95 */
+#define M17_LIT_CLK_MODULUS         2         /* m17_rx_sync.cpp:82   m_clk = (m_clk + 1) % 2 */
+#define M17_LIT_CLK_INIT            1         /* m17_rx_sync.cpp:123 */
+#define M17_LIT_THR_INIT            0         /* m17_rx_sync.cpp:125 */
+#define M17_LIT_INDEX_INIT          10        /* m17_rx_sync.cpp:126 */
+#define M17_LIT_VOTES_UNLOCKED_MAX  0         /* m17_rx_frame.cpp:83  votes > 0 rejects */
+#define M17_LIT_VAR_UNLOCKED        0.3       /* m17_rx_frame.cpp:87  variance < 0.3 (double) */
+#define M17_LIT_VOTES_LOCKED_MAX    1         /* m17_rx_frame.cpp:94 */
+#define M17_LIT_VAR_LOCKED          0.5       /* m17_rx_frame.cpp:98 */
+#define M17_LIT_N_FERROR            5         /* m17_rx_frame.cpp:122 */
+#define M17_LIT_FCLK_AFTER_SYNC     8         /* m17_rx_frame.cpp:166 */
+#define M17_LIT_ACM0                1.0f      /* m17_conv.cpp:153     m_acm[0] = 1.0 */
+#define M17_LIT_TRACEBACK_MASK      0x08      /* m17_conv.cpp:165     out = state & 0x08 */
+#define M17_LIT_GOLAY_FILL_END      0xFFF     /* m17_golay.cpp:53     for (i = 0; i < 0xFFF; ...) -- entry 0xFFF stays 0 */
+#define M17_LIT_GOLAY_UNRECOVERABLE 0x400     /* m17_golay.cpp:54 */
+#define M17_LIT_GOLAY_MAX_BITS      5         /* m17_golay.cpp:61     bits < 5 */
+#define M17_RX_LITERALS { M17_LIT_S16_SCALE, M17_LIT_DEMAP_OFFSET, M17_LIT_DEMAP_COR_NUM, M17_LIT_DEMAP_SYNC_SYMBOLS, M17_LIT_DISC_C, \
+    M17_LIT_DISC_DECIM, M17_LIT_LIMIT_NUM, M17_LIT_THRESH_UNLOCKED, M17_LIT_THRESH_LOCKED, M17_LIT_CLK_MODULUS, M17_LIT_CLK_INIT,    \
+    M17_LIT_THR_INIT, M17_LIT_INDEX_INIT, M17_LIT_VOTES_UNLOCKED_MAX, M17_LIT_VAR_UNLOCKED, M17_LIT_VOTES_LOCKED_MAX,               \
+    M17_LIT_VAR_LOCKED, M17_LIT_N_FERROR, M17_LIT_FCLK_AFTER_SYNC, M17_LIT_ACM0, M17_LIT_TRACEBACK_MASK, M17_LIT_GOLAY_FILL_END,    \
+    M17_LIT_GOLAY_UNRECOVERABLE, M17_LIT_GOLAY_MAX_BITS }
+static_assert(kBlockSamples % M17_LIT_DISC_DECIM == 0 && kDiscOut == kBlockSamples / M17_LIT_DISC_DECIM, "the /5 pick keeps its phase from block to block");
+static_assert(kDiscOut % M17_LIT_CLK_MODULUS == 0 && M17_LIT_CLK_MODULUS == 2 && M17_LIT_TRACEBACK_MASK == 0x08 && M17_LIT_DEMAP_SYNC_SYMBOLS == 8 &&
+              M17_LIT_THR_INIT == 0 && M17_LIT_LIMIT_NUM == 1.0 && M17_LIT_DISC_C == 0.5f,
+              "built into the kernels' structure: two inputs per symbol, bits[t] = state >> 3, eight sync symbols, reciprocal and halving");
+
 #ifdef __HIPCC__
 #define M17_HD __host__ __device__
 #else

@@ -1,7 +1,8 @@
 // m17_fused.hip -- k_rx_chan6: the whole FIR stage of ONE CHANNEL IN ONE WAVE -- int16 IQ -> limiter -> FM discriminator ->
 // /5 -> DC removal (dsp_short_to_float m17_dsp.cpp:136-141, dsp_limit :412-419, dsp_arctan_disc2 :194-222), then the
 // polyphase timing loop (m17_rx_sync_samples m17_rx_sync.cpp:77-99), the sync correlator and the framer
-// (m17_rx_frame.cpp:47-177) -- and k_order, which decides in what order the channels of the next launch are dispatched.
+// (m17_rx_frame.cpp:47-177) -- and k_gate, behind which the decoder of the launch's first channels starts while its last
+// waves are still running.
 //
 // Why one wave runs both phases (DESIGN.md sections 5 and 6): as two kernels the stage's two halves sit on different roofs
 // -- the front end on vector-memory throughput with most of its issue slots idle, the timing loop on issue / dependency
@@ -46,45 +47,34 @@ __device__ unsigned long long g_rc_stamps[16384][4];          // per channel: ti
 // half the registers (sync_wave_channel<1>) -- six waves per SIMD.  Measured: the stage is bound by the
 // vector ALU (~76 % busy) and by its traffic past L2 (4.7-5.1 TB/s), not by what more waves would cover.
 //
-// Dispatch order (round 6).  16,384 waves over 6,144 wave slots are 2.67 generations, and a wave's work varies by +-25 %
-// from channel to channel (how often its timing loop steps between branches, whether its framer hunts): dispatched in
-// channel order, the heaviest channels are as likely last as first, and a slow wave holds its workgroup's LDS while its
-// siblings' slots idle.  `perm` (k_order below; null = channel order) lists the channels by the work their LAST call
-// took, heaviest first: workgroup b serves channels perm[4b .. 4b+3] -- four of one cost class -- and the launch ends on
-// its cheapest waves.  What a channel's wave computes does not depend on where it runs, so results are untouched;
-// `cost` receives this call's work per channel (timing rounds + framer passes) for the next k_order.
+// The tail and the gate (round 6).  16,384 waves over 6,144 wave slots are 2.67 generations: for the last third of the launch's
+// span the slots empty, and its last waves run alone on their SIMDs, latency-bound (residency table in
+// profiles/r05_stamps_rx_chan.txt; neither the dispatch order nor a split of the launch shortens that tail:
+// profiles/r06_dispatch_order_ab.txt, r06_split_call_ab.txt).  The decoder behind it is bound by the vector ALU and needs
+// nothing of the channels still running: so every wave that has finished a channel below `gate_n` -- its records, frame
+// slots and record count written through L2 (OUT_AGENT stores) and complete (s_waitcnt vmcnt(0)) -- adds one to `done`
+// at agent scope, and k_gate, one wave on the context's internal stream, returns when all gate_n have: the work-list,
+// decoder and bookkeeping kernels of those channels are ordered behind it and run in the launch's tail.
 constexpr int RC6_LDS = 6144;                  // per wave: the two 2,304-byte tiles / the timing loop's WvChan (4 KB); a multiple of 2 KB (ring alignment)
 static_assert(RC6_LDS >= 2 * FL_TILE_BYTES && RC6_LDS >= (int)sizeof(WvChan) && RC6_LDS % 2048 == 0, "k_rx_chan6 LDS layout");
 // TAIL: the call's block count is no multiple of sixteen (the host picks the build): only then is there a last group whose
-// tiles the workgroup's channels share, with its barrier and its second look at `perm`.
-template <int TAIL>
+// tiles the workgroup's channels share, with its barrier.
+template <int TAIL, int AG>
 __global__ __launch_bounds__(64 * RC_WAVES, 6)
 void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float *__restrict__ disc, float *__restrict__ offs,
                 int C, int nblk, int mode, m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
                 float *__restrict__ syms, int32_t *__restrict__ nsyms, float *__restrict__ fsym,
-                const int32_t *__restrict__ perm,      // [4 * gridDim.x] channel served by each wave slot of the grid, -1 = none; or null
-                int32_t *__restrict__ cost)            // [C] out, or null
+                uint32_t *__restrict__ done, int gate_n)   // channels [0, gate_n) report to *done when they are finished (null: nobody waits)
 {
     __shared__ __attribute__((aligned(4096))) unsigned char lds[RC_WAVES][RC6_LDS];
     const int wave = uni((int)(threadIdx.x >> 6));
-    const int slot0 = (int)blockIdx.x * RC_WAVES;      // the workgroup's first wave slot (always < C)
-    // the channel of wave slot k of this workgroup, -1 = none (slot 0 always has one)
-    auto wg_chan = [&](int k) {
-        const int c = perm ? uni(perm[slot0 + k]) : slot0 + k;
-        return (unsigned)c < (unsigned)C ? c : -1;
-    };
-    const int chan = wg_chan(wave);
-    int wgch[RC_WAVES] = {0, 0, 0, 0};                  // TAIL: the four of them, for the shared tiles (scalar registers)
-    if constexpr (TAIL != 0) {
-#pragma unroll
-        for (int k = 0; k < RC_WAVES; ++k) wgch[k] = wg_chan(k);
-    }
-    const bool live = chan >= 0;                        // no early exit: a group of fewer than sixteen blocks has a workgroup barrier
+    const int chan0 = (int)blockIdx.x * RC_WAVES;      // the workgroup's first channel (always < C)
+    const int chan = chan0 + wave;
+    const bool live = chan < C;                         // no early exit: a group of fewer than sixteen blocks has a workgroup barrier
     uint32_t *tile = reinterpret_cast<uint32_t *>(lds[wave]);
     float *otile = reinterpret_cast<float *>(lds[wave] + FL_TILE_BYTES);
     WvChan &wc = *reinterpret_cast<WvChan *>(lds[wave]);
     const int row0 = chan * nblk;
-    int work = 0;
 #ifdef M17_STAMPS
     unsigned long long t_fe = 0, t_tm = 0, t_last = __builtin_amdgcn_s_memtime();
     const unsigned long long rt_in = __builtin_amdgcn_s_memrealtime();
@@ -102,16 +92,15 @@ void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float 
         } else {
             // A last group of fewer than sixteen blocks: a tile costs the same whatever it holds, so the 4 x bc rows of the
             // workgroup's four channels are packed into ceil(bc / 4) tiles on its first waves -- row j of that list is block
-            // b0 + j % bc of the workgroup's channel j / bc -- and every wave reads its channel's rows back behind a workgroup barrier
+            // b0 + j % bc of channel chan0 + j / bc -- and every wave reads its channel's rows back behind a workgroup barrier
             // (same CU: the rows are whole cache lines nobody has read yet; the offsets are read at agent scope).
             const int ntile = (RC_WAVES * bc + 15) >> 4;
             if (wave < ntile) {
                 frontend_lite_tile(iq, st, dw, ow, nblk, 1,
                                    [&](int i, bool &valid) {
-                                       const int j = 16 * wave + i, cj = j / bc;
-                                       const int ch = cj == 0 ? wgch[0] : (cj == 1 ? wgch[1] : (cj == 2 ? wgch[2] : (cj == 3 ? wgch[3] : -1)));
-                                       valid = ch >= 0;
-                                       return valid ? ch * nblk + b0 + (j - cj * bc) : wgch[0] * nblk + b0;
+                                       const int j = 16 * wave + i, cj = j / bc, ch = chan0 + cj;
+                                       valid = cj < RC_WAVES && ch < C;
+                                       return valid ? ch * nblk + b0 + (j - cj * bc) : chan0 * nblk + b0;
                                    }, tile, otile, rc_lane());
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -121,8 +110,8 @@ void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float 
         { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fe += now - t_last; t_last = now; }
 #endif
         if (live) {
-            work += sync_wave_channel<1, 1>(dw, ow, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, bc,
-                                            chan, wc, wave, rc_lane());
+            sync_wave_channel<1, 1, AG>(dw, ow, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, bc,
+                                       chan, wc, wave, rc_lane());
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // channel state out before the next group reads it
             wave_lds_sync();
         }
@@ -130,7 +119,10 @@ void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float 
         { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_tm += now - t_last; t_last = now; }
 #endif
     }
-    if (cost && live && lane_id() == 0) cost[chan] = work;
+    // the channel is finished: everything the decoder and the bookkeeping kernel read of it went through L2 (OUT_AGENT) and is
+    // complete (the wait above); one count per channel below gate_n
+    if (AG && done && live && chan < gate_n && lane_id() == 0)
+        __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef M17_STAMPS
     if (live && chan < 16384 && lane_id() == 0) {
         g_rc_stamps[chan][0] = t_fe; g_rc_stamps[chan][1] = t_tm; g_rc_stamps[chan][2] = rt_in; g_rc_stamps[chan][3] = __builtin_amdgcn_s_memrealtime();
@@ -138,35 +130,25 @@ void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float 
 #endif
 }
 
-// k_order: the dispatch order of the next k_rx_chan6 launch -- perm[0 .. C) = the channels by descending cost (a counting
-// sort on min(cost, 1023): one workgroup, LDS histogram, one scan), perm[C .. npad) = -1.  Whatever `cost` holds, perm is a
-// permutation of the channels: every channel is served exactly once; the order inside a cost class is whatever the LDS
-// atomics make it, which nothing observable depends on.
-constexpr int ORD_BINS = 1024;
-__global__ __launch_bounds__(ORD_BINS)
-void k_order(const int32_t *__restrict__ cost, int32_t *__restrict__ perm, int C, int npad)
+// k_gate: one wave that returns when `n` channels have reported to *done (k_rx_chan6), taking them off the counter again
+// -- the target is the same for every call, so a captured graph replays correctly.  It polls at agent scope with the wave
+// asleep in between; kernels enqueued behind it on its stream start with the usual cache invalidation and read what
+// those channels wrote.  A counter that does not arrive within ~4 s of the chip's 100 MHz clock (it always does: the waves
+// it waits for are running, or queued behind nothing that waits) ends the wait with err[0] = 1, which every state getter reports.
+__global__ __launch_bounds__(64)
+void k_gate(uint32_t *__restrict__ done, uint32_t n, uint32_t *__restrict__ err)
 {
-    __shared__ int hist[ORD_BINS], scan[2][ORD_BINS];
-    const int t = (int)threadIdx.x;
-    hist[t] = 0;
-    __syncthreads();
-    auto key = [](int c) { return ORD_BINS - 1 - max(0, min(c, ORD_BINS - 1)); };      // bin 0 = the heaviest
-    for (int i = t; i < C; i += ORD_BINS) atomicAdd(&hist[key(cost[i])], 1);
-    __syncthreads();
-    // exclusive scan of the bins (Hillis-Steele over 1,024 entries)
-    int cur = 0;
-    scan[0][t] = hist[t];
-    __syncthreads();
-    for (int d = 1; d < ORD_BINS; d <<= 1) {
-        const int v = scan[cur][t] + (t >= d ? scan[cur][t - d] : 0);
-        scan[cur ^ 1][t] = v;
-        cur ^= 1;
-        __syncthreads();
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+        __builtin_amdgcn_s_sleep(32);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
     }
-    hist[t] = scan[cur][t] - hist[t];                   // first position of bin t
-    __syncthreads();
-    for (int i = t; i < C; i += ORD_BINS) perm[atomicAdd(&hist[key(cost[i])], 1)] = i;
-    for (int i = C + t; i < npad; i += ORD_BINS) perm[i] = -1;
+    __hip_atomic_fetch_sub(done, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 } // namespace m17dev

@@ -53,7 +53,7 @@ __device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin
 // domain on the device (m17gpu_selftest; run by tests/test_gpu_parity.py).
 
 // dsp_short_to_float (m17_dsp.cpp:136-141): (float)((double)x * 0.00003)
-__device__ __forceinline__ float s16_to_float_ref(int x) { return (float)((double)x * 0.00003); }
+__device__ __forceinline__ float s16_to_float_ref(int x) { return (float)((double)x * M17_LIT_S16_SCALE); }
 // 0.00003 = CHI + CLO + 2.4e-20 with CHI = (float)0.00003.  fma(x, CHI, RN(x*CLO))
 // equals the double-rounded reference for every int16 x (65,536 cases, verified
 // on the host at build-test time and on the device by the self test).
@@ -342,7 +342,7 @@ void k_frontend_q(const uint4 *__restrict__ iq, ChanState *__restrict__ st,
                 const float z1im = (e >= 2) ? pim[e >= 2 ? e - 2 : 0] : (e == 1 ? p0im : p1im);
                 const float aa = z0im * (pre[e] - z1re);
                 const float bb = z0re * (pim[e] - z1im);
-                uh[k] = (bb - aa) * 0.5f;
+                uh[k] = (bb - aa) * M17_LIT_DISC_C;
             }
             *reinterpret_cast<float4 *>(&myf[cbl * FQ_STRIDE + sub * 16 + q * 4]) = make_float4(uh[0], uh[1], uh[2], uh[3]);
         }
@@ -558,7 +558,7 @@ __device__ __forceinline__ void frontend_tile(const uint4 *__restrict__ iq, Chan
             v0 = is3 ? u2[E3] : v0;  v1 = is3 ? u2[E3 + 5] : v1;  v2 = is3 ? u2[E3 + 10] : v2;
             const int e0 = 4 - (C5 * 4 + sub) % 5;
             const int o0 = (C5 * 64 + 16 * sub) / 5;           // output index of the first pick within the period (position e0 is the one with % 5 == 4)
-            const v2f h01 = (v2f){v0, v1} * (v2f){0.5f, 0.5f}, h23 = (v2f){v2, u2[15]} * (v2f){0.5f, 0.5f};
+            const v2f h01 = (v2f){v0, v1} * (v2f){M17_LIT_DISC_C, M17_LIT_DISC_C}, h23 = (v2f){v2, u2[15]} * (v2f){M17_LIT_DISC_C, M17_LIT_DISC_C};
             orow[o0] = h01.x;
             orow[o0 + 1] = h01.y;
             orow[o0 + 2] = h23.x;
@@ -581,7 +581,7 @@ __device__ __forceinline__ void frontend_tile(const uint4 *__restrict__ iq, Chan
         }
         wave_lds_sync();
     }
-    const float offset = dpp_quad_b3(tsum) * 0.5f;
+    const float offset = dpp_quad_b3(tsum) * M17_LIT_DISC_C;
     if (sub0 && valid) {
         offs[cb] = offset / (float)kBlockSamples;
         if (update_state && blk == 0) {
@@ -685,7 +685,7 @@ __device__ __forceinline__ void frontend_quick4p(const uint4 *__restrict__ iq, C
         const int k0 = q == 0 ? 4 : 4 - q;
         const float s1 = q == 4 ? u2[0] : (q == 3 ? u2[1] : (q == 2 ? u2[2] : (q == 1 ? u2[3] : u2[4])));
         const float s2 = q == 4 ? u2[5] : (q == 3 ? u2[6] : u2[7]);
-        const v2f h = (v2f){s1, s2} * (v2f){0.5f, 0.5f};
+        const v2f h = (v2f){s1, s2} * (v2f){M17_LIT_DISC_C, M17_LIT_DISC_C};
         const unsigned oidx = ((unsigned)(128 * c + 8 * l + k0 - 4) * 52429u) >> 18;       // (s - 4) / 5
         if (valid) {
             dst[oidx] = h.x;
@@ -710,7 +710,7 @@ __device__ __forceinline__ void frontend_quick4p(const uint4 *__restrict__ iq, C
     }
     // offset / len (m17_dsp.cpp:213): twice the row's sum sits in lane 0 of `carry`
     if (first && valid) {
-        offs[cb] = (carry * 0.5f) / (float)kBlockSamples;
+        offs[cb] = (carry * M17_LIT_DISC_C) / (float)kBlockSamples;
         if (update_state && blk == 0) {
             st[chan].z0re = n0re; st[chan].z0im = n0im; st[chan].z1re = n1re; st[chan].z1im = n1im;
         }
@@ -860,7 +860,7 @@ __device__ __forceinline__ void frontend_lite_tile(const uint4 *__restrict__ iq,
             v0 = is3 ? u2[E3] : v0;  v1 = is3 ? u2[E3 <= 2 ? E3 + 5 : 7] : v1;
             const int e0 = 4 - (2 * C5 + 3 * sub) % 5;
             const int o0 = (C5 * 32 + 8 * sub + e0) / 5;       // its output index within the period
-            const v2f h = (v2f){v0, v1} * (v2f){0.5f, 0.5f};
+            const v2f h = (v2f){v0, v1} * (v2f){M17_LIT_DISC_C, M17_LIT_DISC_C};
             orow[o0] = h.x;
             if (e0 <= 2) orow[o0 + 1] = h.y;
         }
@@ -881,7 +881,7 @@ __device__ __forceinline__ void frontend_lite_tile(const uint4 *__restrict__ iq,
         }
         wave_lds_sync();
     }
-    const float offset = dpp_quad_b3(tsum) * 0.5f;
+    const float offset = dpp_quad_b3(tsum) * M17_LIT_DISC_C;
     if (sub0 && valid) {
         offs[cb] = offset / (float)kBlockSamples;
         if (update_state && blk == 0) {
@@ -956,7 +956,7 @@ void k_frontend_afc(const uint32_t *__restrict__ iq,      // [C][nblk][1920] pac
         const float2 x = z[2 + i], z0 = z[1 + i], z1 = z[i];
         const float a = z0.y * (x.x - z1.x);               // dsp_arctan_disc2 (m17_dsp.cpp:194-222)
         const float bb = z0.x * (x.y - z1.y);
-        uh[i] = (bb - a) * 0.5f;
+        uh[i] = (bb - a) * M17_LIT_DISC_C;
     }
     __syncthreads();
     for (int k = lane; k < kDiscOut; k += 64) disc_raw[row * kDiscOut + k] = uh[5 * k + 4];
@@ -998,8 +998,8 @@ struct SyncResult { int type; int votes; float variance; };
 // because 0.3f is the float nearest to and above 0.3; 0.5 is exact.
 __device__ __forceinline__ bool sync_accept(const SyncResult &r, bool locked)
 {
-    if (r.votes > (locked ? 1 : 0)) return false;
-    if (r.type >= 1 && r.type <= 4) return (double)r.variance < (locked ? 0.5 : 0.3);
+    if (r.votes > (locked ? M17_LIT_VOTES_LOCKED_MAX : M17_LIT_VOTES_UNLOCKED_MAX)) return false;
+    if (r.type >= 1 && r.type <= 4) return (double)r.variance < (locked ? M17_LIT_VAR_LOCKED : M17_LIT_VAR_UNLOCKED);
     return false;
 }
 
@@ -1042,11 +1042,11 @@ __device__ __forceinline__ void demap16(const float *sym, float *soft, int ln)
     float sum = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) sum += fabsf(sym[i]);
-    const float cor = 8.0f / sum;              // (float)(8.0/(double)sum), see limit()
+    const float cor = (float)M17_LIT_DEMAP_COR_NUM / sum;      // (float)(8.0/(double)sum), see limit()
     for (int i = 8 + ln; i < kFrameSyms; i += 16) {
         const float m = sym[i] * cor;
         soft[2 * (i - 8)]     = -m;
-        soft[2 * (i - 8) + 1] = (float)((double)fabsf(m) - 0.6666);
+        soft[2 * (i - 8) + 1] = (float)((double)fabsf(m) - M17_LIT_DEMAP_OFFSET);
     }
 }
 
@@ -1057,7 +1057,7 @@ __device__ __forceinline__ void viterbi16(const float *dep, int len, uint16_t *d
     const int steps = len >> 1;
     // branch metric selectors (m17_conv.cpp:93-108): metric[idx] = (idx&2 ? m1 : -m1) + (idx&1 ? m2 : -m2)
     const int ie = c_tab.bm_even[ln], io = c_tab.bm_odd[ln];
-    float acm = (ln == 0) ? 1.0f : 0.0f;                 // :150-153
+    float acm = (ln == 0) ? M17_LIT_ACM0 : 0.0f;         // :150-153
     const int grp_shift = (lane_id() & 48);
     for (int t = 0; t < steps; ++t) {
         const float m1 = dep[2 * t], m2 = dep[2 * t + 1];
@@ -1145,8 +1145,8 @@ __global__ void k_reset(ChanState *st, int C)
     uint32_t *p = reinterpret_cast<uint32_t *>(st);
     const int w = i % words;
     uint32_t v = 0;
-    if (w == (int)(offsetof(ChanState, clk) / 4)) v = 1;          // m17_rx_sync.cpp:123
-    if (w == (int)(offsetof(ChanState, index) / 4)) v = 10;       // :126
+    if (w == (int)(offsetof(ChanState, clk) / 4)) v = M17_LIT_CLK_INIT;          // m17_rx_sync.cpp:123
+    if (w == (int)(offsetof(ChanState, index) / 4)) v = M17_LIT_INDEX_INIT;      // :126
     p[i] = v;
 }
 

@@ -193,7 +193,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
             int lockv = known_lock, n = 0;
             for (int attempt = 0; attempt < 2; ++attempt) {
                 // ---- timing recovery in rounds of 64 instants; x[i .. i+30] is the delay line at input i
-                const int thresh = lockv ? 80 : 10;
+                const int thresh = lockv ? M17_LIT_THRESH_LOCKED : M17_LIT_THRESH_UNLOCKED;
                 int p = 0, m_idx = 0;
                 crossed = false;
                 // vote tick on the carried sum/dif (sync_update :38-42, m17_sync_adjust :45-72): the first input of a block
@@ -414,7 +414,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                     else if (sync_accept(r, true)) { flags |= M17_F_SYNC_OK; parse = true; ferr = 0; }
                     else {
                         ferr++;
-                        if (ferr > 5) { flags |= M17_F_LOST; unlock = true; }
+                        if (ferr > M17_LIT_N_FERROR) { flags |= M17_F_LOST; unlock = true; }
                         else parse = true;
                     }
                     if (parse && mode == 1) flags |= M17_F_PARSED;
@@ -440,7 +440,7 @@ void k_sync_frame_duo(const float *__restrict__ disc,     // [C][nblk][384]
                 if (l >= 0) {
                     const int js = pos + l;
                     // copy_sync(); m_fclk = 8; lock; m17_aos(): the window already is the head of the frame
-                    fclk = 8; ferr = 0; flock = 1;
+                    fclk = M17_LIT_FCLK_AFTER_SYNC; ferr = 0; flock = 1;
                     emit_record_wave(crecs, rec_cap, nrec, gl, (uint32_t)r.type | ((uint32_t)r.votes << 8), M17_F_AOS, r.variance,
                                     block_count, (uint32_t)js);
                     nrec++;

@@ -100,10 +100,10 @@ static void build(Tables &T)
             if (d & (0x800 >> b)) p ^= kGolayRows[b];
         T.golay_enc[d] = p;
     }
-    for (int i = 0; i < 0xFFF; ++i) T.golay_err[i] = 0x400;
+    for (int i = 0; i < M17_LIT_GOLAY_FILL_END; ++i) T.golay_err[i] = M17_LIT_GOLAY_UNRECOVERABLE;
     for (uint32_t w = 0; w < (1u << 24); ++w) {
         const int wt = __builtin_popcount(w);
-        if (wt > 4) continue;
+        if (!(wt < M17_LIT_GOLAY_MAX_BITS)) continue;
         const uint16_t data = (uint16_t)(w >> 12);
         const uint16_t syn = (uint16_t)((w & 0xFFF) ^ T.golay_enc[data]);
         T.golay_err[syn] = (uint16_t)((wt << 12) | data);
@@ -213,6 +213,9 @@ extern "C" int m17gpu_get_constant(const char *name, void *out, int cap_bytes)
         put(&T.crc[1], 2);
     } else if (nm == "tx_lut") {                // float [4]
         float lut[4]; m17::tx_deviation_lut(lut); put(lut, sizeof lut);
+    } else if (nm == "rx_literals") {           // double [24]: the streaming arithmetic's literals, in M17_RX_LITERALS' order (m17_dev.h)
+        const double v[] = M17_RX_LITERALS;
+        put(v, sizeof v);
     } else if (nm == "sync_words") {            // uint16 [4]: link setup, stream, packet, BERT
         const uint16_t w[4] = {m17::kSyncLinkSetup, m17::kSyncStream, m17::kSyncPacket, m17::kSyncBert};
         put(w, sizeof w);

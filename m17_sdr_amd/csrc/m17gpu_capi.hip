@@ -66,16 +66,15 @@ struct m17gpu_ctx {
     int fir_impl = 0;                        // 0 = by call (fir_choice); 1 = front end + timing kernel; 4 = wave per channel over sixteen-row
                                              // tiles of its own blocks, rows through the workspace, six waves per SIMD (k_rx_chan6);
                                              // 5 = three waves per channel, the front end one of them (k_sync_frame_duo<1>, up to 1,024 channels)
-    int order_impl = 0;                      // dispatch order of k_rx_chan6: 0 = by measurement (order_choice), 1 = channel order, 2 = by the cost of
-                                             // each channel's last call, heaviest first (k_order)
-    int split_impl = 0;                      // full-chain calls on the wave-per-channel stage: 0 = by measurement (split_choice), 1 = one part,
-                                             // 2..15 = the first split_impl / 16 of the channels as part A: its decoder and bookkeeping run on
-                                             // an internal stream beside the FIR stage of part B
+    int tail_impl = 0;                       // full-chain calls on the wave-per-channel stage: 0 = by measurement (tail_choice), 1 = off, 2..15 = the
+                                             // decoder and bookkeeping of the first tail_impl / 16 of the channels start behind k_gate, on the internal
+                                             // stream, as soon as those channels are finished -- in the tail of k_rx_chan6
     hipStream_t s2 = nullptr;                // the internal stream (non-blocking, highest priority) and the events that fork it from and join it to the caller's
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int32_t *d_cost = nullptr, *d_perm = nullptr;   // [C] work of each channel's last k_rx_chan6 call / [C rounded up to 4] its dispatch order
+    uint32_t *d_gate = nullptr;              // [0] channels finished (k_rx_chan6 adds, k_gate takes off), [1] a gate gave up waiting
+    bool gate_dirty = false;                 // a call got past the k_rx_chan6 launch but not to its k_gate: the counter is not zero
     bool nwork_dirty = false;                // a full-chain call got past k_worklist but not to the bookkeeping kernel that zeroes the counters
-    int last_path[4] = {0, 0, 0, 0};         // what the last m17gpu_rx_blocks call ran: FIR stage (fir_choice), plain slots, bookkeeping kernel, dispatch order
+    int last_path[4] = {0, 0, 0, 0};         // what the last m17gpu_rx_blocks call ran: FIR stage (fir_choice), plain slots, bookkeeping kernel, gated channels
     std::vector<hipEvent_t> ev_pool;         // 7 events per profiled call: 5 stage marks + call start / end
     std::vector<int> ev_mode;                // mode of each profiled call
 };
@@ -283,45 +282,27 @@ int fir_choice(const m17gpu_ctx *ctx, int nblk)
     // profiles/r05_channel_count_crossover.txt)
     return (ctx->C >= 10000 && nblk >= 12) ? 4 : 1;
 }
-// Measured (profiles/r06_dispatch_order_ab.txt): no gain -- the launch's tail is not made by the heavy channels coming last
-// (wave lifetimes differ by when a wave ran, not by what it had to do) -- and k_order costs ~8 us: off unless asked for.
-bool order_choice(const m17gpu_ctx *ctx)
+// Channels whose decoder starts behind the gate (0 = none: one decoder launch behind the whole FIR stage).  k_rx_chan6 ends in a
+// tail (2.67 generations of equal waves; its last waves run alone on their SIMDs, latency-bound) in which a third of the
+// chip's wave slots stand empty; the decoder of the channels that are finished by then fits there.  Whole lines of the
+// per-channel count array (32 channels) so that no line is written through L2 by one part and cached by the other.
+int tail_choice(const m17gpu_ctx *ctx, int nblk, int fir, bool full)
 {
-    return ctx->order_impl == 2;
+    if (!full || fir != 4 || ctx->tail_impl == 1 || !ctx->s2 || ctx->d_net) return 0;
+    const int k = ctx->tail_impl ? ctx->tail_impl : 8;
+    const int a = (int)((long long)ctx->C * k / 16) & ~31;
+    return (a >= 32 && ctx->C - a >= 32) ? a : 0;
 }
-// Channels of part A of a split full-chain call (0 = no split).  k_rx_chan6 ends in a tail -- its last waves run alone on
-// their SIMDs, latency-bound -- and the decoder behind it is bound by the vector ALU: with the channels in two parts,
-// FIR(A), FIR(B) on the caller's stream and decoder + bookkeeping of A on an internal stream behind FIR(A), the decoder
-// of A runs beside FIR(B), whose 0.67 generation of waves leaves it room.
-int split_choice(const m17gpu_ctx *ctx, int nblk, int fir, bool full)
-{
-    if (!full || fir != 4 || ctx->split_impl == 1 || !ctx->s2) return 0;
-    const int k = ctx->split_impl ? ctx->split_impl : 0;
-    if (k == 0) return 0;
-    int a = (int)((long long)ctx->C * k / 16) & ~7;
-    return (a >= 8 && ctx->C - a >= 8) ? a : 0;
-}
-// the wave-per-channel FIR stage (k_rx_chan6) over the channel range [c0, c0 + cn)
+// the wave-per-channel FIR stage (k_rx_chan6); channels [0, gate_n) report to the context's gate counter
 int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
-                 int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st, int c0 = 0, int cn = -1)
+                 int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st, int gate_n)
 {
-    if (cn < 0) cn = ctx->C;
     mode |= plain_slots(ctx, nblk) ? 16 : 0;                         // bit 4: plain frame slots
-    const int grid = cdiv(cn, RC_WAVES);
-    const bool order = order_choice(ctx);
-    int32_t *perm = ctx->d_perm + (c0 + 3) / 4 * 4, *cost = ctx->d_cost + c0;       // (ranges start on multiples of four)
-    if (order) {
-        // the range's channels by the work their last call took, heaviest first (channel numbers relative to the range)
-        hipLaunchKernelGGL(k_order, dim3(1), dim3(ORD_BINS), 0, st, cost, perm, cn, grid * RC_WAVES);
-        HIPCHK(hipGetLastError());
-    }
-    hipLaunchKernelGGL((nblk % 16) ? k_rx_chan6<1> : k_rx_chan6<0>, dim3(grid), dim3(64 * RC_WAVES), 0, st,
-                       reinterpret_cast<const uint4 *>(d_iq) + (size_t)c0 * nblk * (kBlockSamples / 4), ctx->d_state + c0,
-                       ctx->d_disc + (size_t)c0 * nblk * kDiscOut, ctx->d_offs + (size_t)c0 * nblk, cn, nblk, mode,
-                       d_recs ? reinterpret_cast<m17gpu_rec_dev *>(d_recs) + (size_t)c0 * rec_cap : nullptr, d_recs ? rec_cap : 0,
-                       (d_counts ? d_counts : ctx->d_counts) + c0,
-                       d_syms ? d_syms + (size_t)c0 * M17_SYM_STRIDE(nblk) : nullptr, d_nsyms ? d_nsyms + (size_t)c0 * nblk : nullptr,
-                       ctx->d_fsym + (size_t)c0 * rec_cap * kSlotFloats, order ? perm : nullptr, cost);
+    auto kern = gate_n ? ((nblk % 16) ? k_rx_chan6<1, 1> : k_rx_chan6<0, 1>) : ((nblk % 16) ? k_rx_chan6<1, 0> : k_rx_chan6<0, 0>);
+    hipLaunchKernelGGL(kern, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
+                       reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->C, nblk, mode,
+                       reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
+                       d_syms, d_nsyms, ctx->d_fsym, gate_n ? ctx->d_gate : nullptr, gate_n);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -414,8 +395,7 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     ALLOC(ctx->d_fsym, sizeof(float) * (size_t)n_channels * ctx->rec_cap_max * kSlotFloats);
     ALLOC(ctx->d_work, sizeof(int32_t) * 3 * (size_t)n_channels * ctx->rec_cap_max);   // one list per frame type (decode_impl 2)
     ALLOC(ctx->d_nwork, sizeof(int32_t) * 8);
-    ALLOC(ctx->d_cost, sizeof(int32_t) * (size_t)n_channels);
-    ALLOC(ctx->d_perm, sizeof(int32_t) * ((size_t)n_channels + 8));
+    ALLOC(ctx->d_gate, sizeof(uint32_t) * 2);
     ALLOC(ctx->d_counts, sizeof(int32_t) * (size_t)n_channels);
     ALLOC(ctx->d_dec_hist, sizeof(uint32_t) * 32 * (size_t)n_channels);
 #undef ALLOC
@@ -446,7 +426,7 @@ void m17gpu_destroy(m17gpu_ctx *ctx)
     DeviceScope dev_scope_(ctx->device);
     void *bufs[] = {ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->d_fsym, ctx->d_work,
                     ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis, ctx->d_dec_hist, ctx->d_flags,
-                    ctx->d_cost, ctx->d_perm};
+                    ctx->d_gate};
     for (void *p : bufs) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->s2) { (void)hipStreamSynchronize(ctx->s2); (void)hipStreamDestroy(ctx->s2); }
@@ -464,8 +444,8 @@ int m17gpu_reset(m17gpu_ctx *ctx, void *stream)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(ctx->d_dec_hist, 0, sizeof(uint32_t) * 32 * (size_t)ctx->C, S(stream)));
     HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t) * 8, S(stream)));
-    HIPCHK(hipMemsetAsync(ctx->d_cost, 0, sizeof(int32_t) * (size_t)ctx->C, S(stream)));      // no history: channel order
-    ctx->nwork_dirty = false;
+    HIPCHK(hipMemsetAsync(ctx->d_gate, 0, sizeof(uint32_t) * 2, S(stream)));
+    ctx->nwork_dirty = false; ctx->gate_dirty = false;
     return M17GPU_OK;
 }
 
@@ -497,8 +477,8 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
     }
     const int fir = fir_choice(ctx, nblk);
     ctx->last_path[0] = fir; ctx->last_path[1] = plain_slots(ctx, nblk) ? 1 : 0; ctx->last_path[2] = 0;
-    ctx->last_path[3] = (fir == 4 && order_choice(ctx)) ? 1 : 0;
-    const int split_a = split_choice(ctx, nblk, fir, full);
+    const int gate_n = tail_choice(ctx, nblk, fir, full);
+    ctx->last_path[3] = gate_n;
     hipEvent_t *ev = nullptr;
     if (ctx->profiling && ctx->ev_mode.size() < 512) {
         const size_t base = ctx->ev_pool.size();
@@ -532,12 +512,13 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
             MARK(2);
         } else if (fir == 4) {
             MARK(1);                             // no separate front end: stage 0 reads as zero, stage 1 is the wave-per-channel kernel
-            if (split_a) {
-                if ((rc = launch_fused(ctx, d_iq, nblk, mode, d_recs, rec_cap, d_counts, d_syms, d_nsyms, st, 0, split_a)) != M17GPU_OK) return rc;
+            if (gate_n) {
+                // the gate counter is zero here (k_gate takes off what it waited for) unless a call failed between its FIR launch and its gate
+                if (ctx->gate_dirty) HIPCHK(hipMemsetAsync(ctx->d_gate, 0, sizeof(uint32_t), st));
                 HIPCHK(hipEventRecord(ctx->ev_fork, st));
-                if ((rc = launch_fused(ctx, d_iq, nblk, mode, d_recs, rec_cap, d_counts, d_syms, d_nsyms, st, split_a, ctx->C - split_a)) != M17GPU_OK) return rc;
-            } else
-            if ((rc = launch_fused(ctx, d_iq, nblk, mode, d_recs, rec_cap, d_counts, d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
+                ctx->gate_dirty = true;
+            }
+            if ((rc = launch_fused(ctx, d_iq, nblk, mode, d_recs, rec_cap, d_counts, d_syms, d_nsyms, st, gate_n)) != M17GPU_OK) return rc;
             MARK(2);
         } else {
             if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, st)) != M17GPU_OK) return rc;
@@ -546,14 +527,18 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
                                         d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
             MARK(2);
         }
-        if (full && split_a) {
-            // part A's decoder and bookkeeping on the internal stream, behind FIR(A) and beside FIR(B); part B's on the
-            // caller's stream, which then waits for the internal one: everything of the call is complete on `stream`
+        if (full && gate_n) {
+            // channels [0, gate_n): work list, decoder and bookkeeping on the internal stream, behind the gate -- they start
+            // while k_rx_chan6's last waves are still running; the rest on the caller's stream behind the kernel, which then waits
+            // for the internal stream: everything of the call is complete on `stream`
             const bool plain = plain_slots(ctx, nblk);
             HIPCHK(hipStreamWaitEvent(ctx->s2, ctx->ev_fork, 0));
-            if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, ctx->s2, 0, split_a, 0, nullptr, plain)) != M17GPU_OK) return rc;
+            hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, ctx->s2, ctx->d_gate, (uint32_t)gate_n, ctx->d_gate + 1);
+            HIPCHK(hipGetLastError());
+            ctx->gate_dirty = false;
+            if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, ctx->s2, 0, gate_n, 0, nullptr, plain)) != M17GPU_OK) return rc;
             HIPCHK(hipEventRecord(ctx->ev_join, ctx->s2));
-            if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, st, split_a, ctx->C - split_a, 1, ev ? ev[3] : nullptr, plain)) != M17GPU_OK) return rc;
+            if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, st, gate_n, ctx->C - gate_n, 1, ev ? ev[3] : nullptr, plain)) != M17GPU_OK) return rc;
             HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
             ctx->nwork_dirty = false;
             MARK(4);
@@ -667,8 +652,15 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     if (!std::strcmp(name, "sync_impl")) { if (value != 0 && value != 6 && value != 8) return bad(); ctx->sync_impl = value; }
     else if (!std::strcmp(name, "fe_impl")) { if (value != 0 && (value < 2 || value > 4)) return bad(); ctx->fe_impl = value; }
     else if (!std::strcmp(name, "fir_impl")) { if (value != 0 && value != 1 && value != 4 && value != 5) return bad(); ctx->fir_impl = value; }
-    else if (!std::strcmp(name, "split_impl")) { if (value < 0 || value > 15) return bad(); ctx->split_impl = value; }
-    else if (!std::strcmp(name, "order_impl")) { if (value < 0 || value > 2) return bad(); ctx->order_impl = value; }
+    else if (!std::strcmp(name, "tail_impl")) { if (value < 0 || value > 15) return bad(); ctx->tail_impl = value; }
+    else if (!std::strcmp(name, "tail_prio")) {            // EXPERIMENT: priority of the internal stream, 0 = lowest, 1 = highest
+        if (value != 0 && value != 1) return bad();
+        ON_CTX_DEVICE(ctx);
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        if (ctx->s2) { HIPCHK(hipStreamSynchronize(ctx->s2)); HIPCHK(hipStreamDestroy(ctx->s2)); ctx->s2 = nullptr; }
+        HIPCHK(hipStreamCreateWithPriority(&ctx->s2, hipStreamNonBlocking, value ? hi : lo));
+    }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
     else if (!std::strcmp(name, "slot_impl")) { if (value < 0 || value > 2) return bad(); ctx->slot_impl = value; }
     else if (!std::strcmp(name, "book_impl")) { if (value < 0 || value > 2) return bad(); ctx->book_impl = value; }
@@ -1251,6 +1243,9 @@ static int fetch_state(m17gpu_ctx *ctx, std::vector<ChanState> &h)
     h.resize((size_t)ctx->C);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(h.data(), ctx->d_state, sizeof(ChanState) * (size_t)ctx->C, hipMemcpyDeviceToHost));
+    uint32_t gate[2] = {0, 0};
+    HIPCHK(hipMemcpy(gate, ctx->d_gate, sizeof gate, hipMemcpyDeviceToHost));
+    if (gate[1]) return fail(M17GPU_ERR_HIP, "a decoder gate gave up waiting for its channels (k_gate): the results of that call are incomplete");
     return M17GPU_OK;
 }
 

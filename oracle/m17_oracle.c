@@ -15,6 +15,42 @@
 #include <stdlib.h>
 #include "m17_oracle.h"
 
+/* The literals and control constants of the reference's streaming arithmetic, each under ONE name: the code below uses
+ * these names where the reference has the literal, and m17o_get_constant("rx_literals") returns them in this order --
+ * tests/test_ref_constants.py holds that array against the values found in the reference's source text
+ * (tests/golden/extract_ref_constants.py) and against the product's. */
+#define M17O_LIT_S16_SCALE           0.00003   /* m17_dsp.cpp:138-139 */
+#define M17O_LIT_DEMAP_OFFSET        0.6666    /* m17_dsp.cpp:41 */
+#define M17O_LIT_DEMAP_COR_NUM       8.0       /* m17_dsp.cpp:88 */
+#define M17O_LIT_DEMAP_SYNC_SYMBOLS  8         /* m17_dsp.cpp:85 */
+#define M17O_LIT_DISC_C              0.5f      /* m17_dsp.cpp:199 */
+#define M17O_LIT_DISC_DECIM          5         /* m17_dsp.cpp:207 */
+#define M17O_LIT_LIMIT_NUM           1.0       /* m17_dsp.cpp:415 */
+#define M17O_LIT_THRESH_UNLOCKED     10        /* m17_rx_sync.cpp:93 */
+#define M17O_LIT_THRESH_LOCKED       80        /* m17_rx_sync.cpp:95 */
+#define M17O_LIT_CLK_MODULUS         2         /* m17_rx_sync.cpp:82 */
+#define M17O_LIT_CLK_INIT            1         /* m17_rx_sync.cpp:123 */
+#define M17O_LIT_THR_INIT            0         /* m17_rx_sync.cpp:125 */
+#define M17O_LIT_INDEX_INIT          10        /* m17_rx_sync.cpp:126 */
+#define M17O_LIT_VOTES_UNLOCKED_MAX  0         /* m17_rx_frame.cpp:83 */
+#define M17O_LIT_VAR_UNLOCKED        0.3       /* m17_rx_frame.cpp:87 */
+#define M17O_LIT_VOTES_LOCKED_MAX    1         /* m17_rx_frame.cpp:94 */
+#define M17O_LIT_VAR_LOCKED          0.5       /* m17_rx_frame.cpp:98 */
+#define M17O_LIT_N_FERROR            5         /* m17_rx_frame.cpp:122 */
+#define M17O_LIT_FCLK_AFTER_SYNC     8         /* m17_rx_frame.cpp:166 */
+#define M17O_LIT_ACM0                1.0f      /* m17_conv.cpp:153 */
+#define M17O_LIT_TRACEBACK_MASK      0x08      /* m17_conv.cpp:165 */
+#define M17O_LIT_GOLAY_FILL_END      0xFFF     /* m17_golay.cpp:53 */
+#define M17O_LIT_GOLAY_UNRECOVERABLE 0x400     /* m17_golay.cpp:54 */
+#define M17O_LIT_GOLAY_MAX_BITS      5         /* m17_golay.cpp:61 */
+static const double t_rx_literals[24] = {
+    M17O_LIT_S16_SCALE, M17O_LIT_DEMAP_OFFSET, M17O_LIT_DEMAP_COR_NUM, M17O_LIT_DEMAP_SYNC_SYMBOLS, M17O_LIT_DISC_C,
+    M17O_LIT_DISC_DECIM, M17O_LIT_LIMIT_NUM, M17O_LIT_THRESH_UNLOCKED, M17O_LIT_THRESH_LOCKED, M17O_LIT_CLK_MODULUS,
+    M17O_LIT_CLK_INIT, M17O_LIT_THR_INIT, M17O_LIT_INDEX_INIT, M17O_LIT_VOTES_UNLOCKED_MAX, M17O_LIT_VAR_UNLOCKED,
+    M17O_LIT_VOTES_LOCKED_MAX, M17O_LIT_VAR_LOCKED, M17O_LIT_N_FERROR, M17O_LIT_FCLK_AFTER_SYNC, M17O_LIT_ACM0,
+    M17O_LIT_TRACEBACK_MASK, M17O_LIT_GOLAY_FILL_END, M17O_LIT_GOLAY_UNRECOVERABLE, M17O_LIT_GOLAY_MAX_BITS };
+
+
 /* ------------------------------------------------------------------ */
 /* tables                                                             */
 /* ------------------------------------------------------------------ */
@@ -103,10 +139,10 @@ static void build_golay(void)
         t_genc[i] = p;
     }
     memset(t_gerr, 0, sizeof t_gerr);
-    for (int i = 0; i < 0xFFF; i++) t_gerr[i] = 0x400;       /* :53-55 as written */
+    for (int i = 0; i < M17O_LIT_GOLAY_FILL_END; i++) t_gerr[i] = M17O_LIT_GOLAY_UNRECOVERABLE;       /* :53-55 as written */
     for (uint32_t w = 0; w < 0x1000000u; w++) {
         int bits = __builtin_popcount(w);
-        if (bits < 5) {
+        if (bits < M17O_LIT_GOLAY_MAX_BITS) {
             uint16_t data = (uint16_t)(w >> 12), par = (uint16_t)(w & 0xFFF);
             uint16_t syn = par ^ t_genc[data];
             t_gerr[syn] = (uint16_t)((bits << 12) | data);
@@ -186,6 +222,7 @@ int m17o_get_constant(const char *name, void *out, int cap)
     uint8_t buf[256];
     int n = 0;
     m17o_init();
+    if (!strcmp(name, "rx_literals")) { memcpy(buf, t_rx_literals, sizeof t_rx_literals); n = sizeof t_rx_literals; } else
     if (!strcmp(name, "sframe")) { memcpy(buf, t_sframe, sizeof t_sframe); n = sizeof t_sframe; }
     else if (!strcmp(name, "derand_bytes")) { memcpy(buf, t_ctab, 46); n = 46; }
     else if (!strcmp(name, "golay_rows")) { memcpy(buf, t_gtab, sizeof t_gtab); n = sizeof t_gtab; }
@@ -210,9 +247,9 @@ int m17o_sizeof_chan(void) { return (int)sizeof(m17o_chan); }
 void m17o_chan_reset(m17o_chan *st)
 {
     memset(st, 0, sizeof *st);
-    st->m_clk = 1;
-    st->m_thr = 0;
-    st->m_index = 10;
+    st->m_clk = M17O_LIT_CLK_INIT;
+    st->m_thr = M17O_LIT_THR_INIT;
+    st->m_index = M17O_LIT_INDEX_INIT;
 }
 
 /* ------------------------------------------------------------------ */
@@ -345,7 +382,7 @@ int m17o_viterbi_decode(const float *in, uint8_t *out, int len)
     static __thread uint8_t path[16][1024];
     int hp = 0;
     memset(acm, 0, sizeof acm);
-    acm[0] = 1.0f;
+    acm[0] = M17O_LIT_ACM0;
     for (int i = 0; i < len; i += 2) {
         float m1 = in[i], m2 = in[i + 1];
         float metric1X = m1, metric0X = -m1, metricX1 = m2, metricX0 = -m2;
@@ -367,7 +404,7 @@ int m17o_viterbi_decode(const float *in, uint8_t *out, int len)
     uint8_t state = 0;
     for (int i = hp - 1; i >= 0; i--) {
         state = path[state][i];
-        out[i] = (state & 0x08) ? 1 : 0;
+        out[i] = (state & M17O_LIT_TRACEBACK_MASK) ? 1 : 0;
     }
     return hp;
 }
@@ -395,13 +432,13 @@ int m17o_pack_1_to_8(const uint8_t *in, uint8_t *out, int len)
 void m17o_demap_frame(const float *in, float *out)
 {
     float sum = 0;
-    for (int i = 0; i < 8; i++) sum += fabsf(in[i]);
-    float cor = (float)(8.0 / (double)sum);
+    for (int i = 0; i < M17O_LIT_DEMAP_SYNC_SYMBOLS; i++) sum += fabsf(in[i]);
+    float cor = (float)(M17O_LIT_DEMAP_COR_NUM / (double)sum);
     int idx = 0;
     for (int i = 8; i < M17O_FRAME_SYMS; i++) {
         float m = in[i] * cor;
         out[idx]     = -m;
-        out[idx + 1] = (float)((double)fabsf(m) - 0.6666);
+        out[idx + 1] = (float)((double)fabsf(m) - M17O_LIT_DEMAP_OFFSET);
         idx += 2;
     }
 }
@@ -502,8 +539,8 @@ void m17o_frontend(m17o_chan *st, const int16_t *iq, float *d, float *d_raw, flo
         else st->afc_delta = 0;
     }
     for (int i = 0; i < M17O_BLOCK_SAMPLES; i++) {
-        float re = (float)((double)iq[2 * i] * 0.00003);
-        float im = (float)((double)iq[2 * i + 1] * 0.00003);
+        float re = (float)((double)iq[2 * i] * M17O_LIT_S16_SCALE);
+        float im = (float)((double)iq[2 * i + 1] * M17O_LIT_S16_SCALE);
         if (st->afc_on) {
             float c = (float)cos(acc);
             float s = (float)sin(acc);
@@ -513,7 +550,7 @@ void m17o_frontend(m17o_chan *st, const int16_t *iq, float *d, float *d_raw, flo
             re = mre; im = mim;
         }
         float m = sqrtf(re * re + im * im);
-        float g = (float)(1.0 / (double)m);
+        float g = (float)(M17O_LIT_LIMIT_NUM / (double)m);
         re = re * g;
         im = im * g;
         float a = z0im * (re - z1re);
@@ -521,9 +558,9 @@ void m17o_frontend(m17o_chan *st, const int16_t *iq, float *d, float *d_raw, flo
         float u = b - a;
         z1re = z0re; z1im = z0im;
         z0re = re;   z0im = im;
-        count = (count + 1) % 5;
-        if (count == 0) d[idx++] = u * 0.5f;
-        offset += u * 0.5f;
+        count = (count + 1) % M17O_LIT_DISC_DECIM;
+        if (count == 0) d[idx++] = u * M17O_LIT_DISC_C;
+        offset += u * M17O_LIT_DISC_C;
     }
     if (st->afc_on) {
         double ip;
@@ -563,7 +600,7 @@ int m17o_rx_sync_samples(m17o_chan *st, const float *in, float *out, int len)
     for (int i = 0; i < len; i++) {
         for (int k = 0; k < M17O_FN - 1; k++) st->m_buff[k] = st->m_buff[k + 1];
         st->m_buff[M17O_FN - 1] = in[i];
-        st->m_clk = (st->m_clk + 1) % 2;
+        st->m_clk = (st->m_clk + 1) % M17O_LIT_CLK_MODULUS;
         if (st->m_clk) {
             st->sum = sync_filter(st->m_buff, t_mf[st->m_index]);
             st->dif = sync_filter(st->m_buff, t_md[st->m_index]);
@@ -574,7 +611,7 @@ int m17o_rx_sync_samples(m17o_chan *st, const float *in, float *out, int len)
             if (sum < 0) dif = -dif;
             if (dif > 0) st->m_thr++;
             if (dif < 0) st->m_thr--;
-            int thresh = st->m_flock ? 80 : 10;
+            int thresh = st->m_flock ? M17O_LIT_THRESH_LOCKED : M17O_LIT_THRESH_UNLOCKED;
             if (st->m_thr > thresh) {
                 st->m_index = (st->m_index + 1) % M17O_NF;
                 st->m_thr = 0;
@@ -634,9 +671,9 @@ void m17o_sync_check(const float *vect, uint8_t *type, uint8_t *votes, float *va
 /* m17_rx_frame.cpp:82-103; the literals 0.3 / 0.5 are doubles there */
 static int sync_ok(uint8_t type, uint8_t votes, float variance, int locked)
 {
-    if (votes > (locked ? 1 : 0)) return 0;
+    if (votes > (locked ? M17O_LIT_VOTES_LOCKED_MAX : M17O_LIT_VOTES_UNLOCKED_MAX)) return 0;
     if (type == 1 || type == 2 || type == 3 || type == 4)
-        if ((double)variance < (locked ? 0.5 : 0.3)) return 1;
+        if ((double)variance < (locked ? M17O_LIT_VAR_LOCKED : M17O_LIT_VAR_UNLOCKED)) return 1;
     return 0;
 }
 
@@ -799,7 +836,7 @@ static int rx_symbols(m17o_chan *st, const float *sym, int len, m17o_rec *recs, 
                     st->m_frame_errors = 0;
                 } else {
                     st->m_frame_errors++;
-                    if (st->m_frame_errors > 5) {
+                    if (st->m_frame_errors > M17O_LIT_N_FERROR) {
                         st->m_flock = 0; reset_sync(st); do_los(st);
                         r->flags |= M17O_F_LOST;
                     } else if (parse) {
@@ -814,7 +851,7 @@ static int rx_symbols(m17o_chan *st, const float *sym, int len, m17o_rec *recs, 
             m17o_sync_check(st->m_sync, &type, &votes, &var);
             if (sync_ok(type, votes, var, 0)) {
                 for (int k = 0; k < 8; k++) st->m_f_sym[k] = st->m_sync[k];
-                st->m_fclk = 8;
+                st->m_fclk = M17O_LIT_FCLK_AFTER_SYNC;
                 st->m_frame_errors = 0;
                 st->m_flock = 1;
                 do_aos(st);

@@ -34,6 +34,12 @@ def test_bench_starts_its_own_ranks_gloo_rehearsal():
     fan = line["fanout"]
     assert 96 * 4 < fan["records_bytes_per_rank"] < fan["records_bytes_unpacked"] * 6 // 10, fan
     assert line["with_fanout"]["ms_per_step"] > 0 and line["with_fanout_overlapped"]["ms_per_step"] > 0
+    # who took part: every rank's device and channel range, the group's own size; what a caller gets beside what the kernels take
+    assert [r["rank"] for r in line["ranks"]] == [0, 1] and [r["shard_range"] for r in line["ranks"]] == [[0, 96], [96, 192]]
+    assert all(r["pci_bus_id"] for r in line["ranks"]) and line["collectives"]["world_size"] == 2
+    assert line["collectives"]["distinct_devices"] == 1                     # the rehearsal: two ranks on this box's one card
+    assert 0 < line["roofline"]["frac_wall"] <= line["roofline"]["frac"] * 1.02 and line["roofline"]["path"]["fir"] in (1, 5)
+    assert 0 < line["fir_stage"]["frac_wall"] and line["fir_stage"]["path"]["fir"] == 5
 
 
 def test_bench_drives_the_capi_fanout_entries():
@@ -54,6 +60,10 @@ def test_bench_drives_the_capi_fanout_entries():
     assert fan["transport"].startswith("C-ABI") and fan["fanout_ms"] > 0 and fan["gather_ms"] > 0
     assert 128 * 4 < fan["records_bytes_per_rank"] < fan["records_bytes_unpacked"] * 6 // 10
     assert line["with_fanout_overlapped"]["ms_per_step"] > 0
+    # RCCL's own view of the communicator the legs ran on (degenerate at one rank), next to the rank table
+    assert line["collectives"]["ncclCommCount"] == 1 and fan["ncclCommCount"] == 1 and fan["ncclCommCuDevice"] == 0
+    assert len(line["ranks"]) == 1 and line["ranks"][0]["shard_range"] == [0, 128] and line["ranks"][0]["pci_bus_id"]
+    assert line["roofline"]["frac_wall"] > 0
 
 
 def test_bench_line_survives_a_failing_fanout_leg():
@@ -72,14 +82,15 @@ def test_bench_line_survives_a_failing_fanout_leg():
 
 def test_bench_line_survives_a_hanging_fanout_leg():
     """A transfer leg that never returns on one rank (its peer then waits in the agreement all-reduce for ever) must
-    not cost the measurement either: the watchdog prints the line without the legs and ends every rank."""
+    not cost the measurement either: the watchdog prints the line without the legs and ends every rank -- with an exit
+    code of its own (3: neither "clean" nor a crash), which the rank launcher passes on together with the line."""
     env = dict(os.environ, M17_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4", M17_BENCH_INJECT_FANOUT_HANG="1",
                M17_BENCH_FANOUT_TIMEOUT="8")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--channels", "64", "--blocks", "4", "--no-cpu-baseline", "--no-noisy"],
                        env=env, capture_output=True, text=True, timeout=150)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 3, (r.returncode, r.stdout[-2000:] + r.stderr[-2000:])
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"]["frac"] > 0
     assert "did not finish" in line["fanout"]["fanout_error"] and "with_fanout" not in line

@@ -236,7 +236,7 @@ def test_exact_arithmetic_selftest():
 
 
 @pytest.mark.parametrize("options", [
-    {"sync_impl": 8}, {"fe_impl": 3, "fir_impl": 1}, {"fe_impl": 4, "fir_impl": 1}, {"fir_impl": 1}, {"fir_impl": 4}, {"fir_impl": 4, "order_impl": 1},
+    {"sync_impl": 8}, {"fe_impl": 3, "fir_impl": 1}, {"fe_impl": 4, "fir_impl": 1}, {"fir_impl": 1}, {"fir_impl": 4}, {"fir_impl": 4, "tail_impl": 1},
     {"fir_impl": 5}, {"fir_impl": 1, "sync_impl": 8}, {"slot_impl": 1}, {"slot_impl": 2}, {"book_impl": 1}, {"book_impl": 2},
     {"book_impl": 2, "fir_impl": 4}, {"slot_impl": 2, "fir_impl": 4}])
 def test_every_kernel_variant_is_bit_exact(options):
@@ -290,7 +290,7 @@ def test_config2_1024_channels_front_end_bit_exact():
 
 
 @pytest.mark.parametrize("ebn0,options,nblk", [(4.0, {}, 12), (8.0, {}, 12), (12.0, {}, 12), (10.0, {"fir_impl": 1}, 12), (10.0, {"fe_impl": 3, "fir_impl": 1}, 12),
-                                               (8.0, {}, 16), (200.0, {}, 16), (10.0, {"slot_impl": 2}, 16), (10.0, {"order_impl": 1}, 16)])
+                                               (8.0, {}, 16), (200.0, {}, 16), (10.0, {"slot_impl": 2}, 16), (10.0, {"tail_impl": 1}, 16), (6.0, {"tail_impl": 13}, 16)])
 def test_config4_16384_channels_awgn_bit_exact(ebn0, options, nblk):
     """BASELINE configs[3] at its real size: 16,384 channels on one GPU, band-limited AWGN, signal from
     the device generator (every channel distinct), DEFAULT options -- so the kernels the bench runs at this size
@@ -373,51 +373,6 @@ def test_fir_stage_at_the_size_the_roofline_figure_is_quoted_on(C, nblk, ebn0):
     np.testing.assert_array_equal(np.ascontiguousarray(st["m_buff"][:, 1:]).view(np.uint32),
                                   np.ascontiguousarray(och.field("m_buff")[:, 1:]).view(np.uint32), err_msg="m_buff")
     rx.close()
-
-
-def test_dispatch_order_is_a_permutation_and_changes_nothing():
-    """k_rx_chan6 serves its channels in the order k_order makes from the work each channel's last call took (heaviest
-    first).  Whatever that order is, every channel must be served exactly once and get the results
-    it gets in channel order: one stream in several calls (the order changes from call to call: channels lose and regain
-    lock at 9 dB) on a context with the order on and one with it off, both against the oracle; ragged channel count (the
-    last workgroup has three wave slots without a channel), calls of whole tiles and with a shared last group."""
-    torch = _torch()
-    import m17_sdr_amd as m
-    C, lengths = 10001, (16, 16, 12, 32, 20)
-    total = sum(lengths)
-    gen = m.Receiver(C, total)
-    iq_all = gen.gen_batch(total, n_stream_frames=9, ebn0_db=9.0, noise_cutoff_hz=6250.0)["iq"]
-    gen.close()
-    iq_host = iq_all.cpu().numpy()
-    rxs = [m.Receiver(C, max(lengths)) for _ in range(2)]
-    for rx, o in zip(rxs, (2, 1)):
-        rx.set_option("fir_impl", 4)
-        rx.set_option("order_impl", o)
-    och = oracle.Channels(C)
-    at = 0
-    for nblk in lengths:
-        part = iq_all[:, at:at + nblk].contiguous()
-        ref = och.rx_blocks(np.ascontiguousarray(iq_host[:, at:at + nblk]), mode=1, nthreads=16, cap=rxs[0].rec_cap_max)
-        at += nblk
-        for rx, ordered in zip(rxs, (1, 0)):
-            out = rx.rx_blocks(part, 1, rx.alloc_outputs(nblk, want_syms=True))
-            torch.cuda.synchronize()
-            assert rx.last_path()["fir"] == 4 and rx.last_path()["ordered"] == ordered, rx.last_path()
-            counts = out["counts"].cpu().numpy()
-            np.testing.assert_array_equal(counts, ref["counts"])
-            np.testing.assert_array_equal(out["nsyms"].cpu().numpy(), ref["nsyms"])
-            np.testing.assert_array_equal(out["syms"].cpu().numpy().view(np.uint32), ref["syms"].view(np.uint32))
-            recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
-            cap = recs.shape[1]
-            valid = np.arange(cap)[None, :] < counts[:, None]
-            g = recs.view(np.uint8).reshape(C, cap, 64)[valid]
-            r = ref["recs"].view(np.uint8).reshape(C, cap, 64)[valid]
-            bad = np.nonzero((g != r).any(axis=1))[0]
-            assert bad.size == 0, (nblk, ordered, bad[:5], g[bad[:1]], r[bad[:1]])
-            np.testing.assert_array_equal(rx.lsf(), och.field("m_lsf"))
-            np.testing.assert_array_equal(rx.counters(), och.field("counters"))
-    for rx in rxs:
-        rx.close()
 
 
 def test_config5_total_channel_count_on_one_gpu_bit_exact():
@@ -729,14 +684,14 @@ def test_set_option_rejects_unknown_and_out_of_range_values():
     for name, value in (("fe_impl", 101), ("fe_impl", 107), ("fe_impl", -1), ("fe_impl", 5), ("fe_impl", 1), ("sync_impl", 2),
                         ("sync_impl", 5), ("sync_impl", 1), ("sync_impl", 4), ("sync_impl", 10), ("sync_impl", 7), ("sync_impl", 9),
                         ("fir_impl", 6), ("fir_impl", -1), ("fir_impl", 2), ("fir_impl", 3),         # removed in round 6: no longer reachable
-                        ("slot_impl", 3), ("book_impl", 3), ("order_impl", 3), ("order_impl", -1),
+                        ("slot_impl", 3), ("book_impl", 3), ("tail_impl", 16), ("tail_impl", -1), ("order_impl", 1), ("split_impl", 8),
                         ("overlap_chunks", 2), ("fe_waves_per_cu", 8), ("lanes_per_channel", 16),
                         ("decode_impl", 0), ("no_such_option", 1)):
         with pytest.raises(RuntimeError):
             rx.set_option(name, value)
     for name, value in (("fe_impl", 0), ("fe_impl", 2), ("fe_impl", 3), ("fe_impl", 4), ("sync_impl", 0), ("sync_impl", 6), ("sync_impl", 8),
                         ("fir_impl", 0), ("fir_impl", 1), ("fir_impl", 4), ("fir_impl", 5), ("slot_impl", 1), ("slot_impl", 2), ("slot_impl", 0),
-                        ("book_impl", 1), ("book_impl", 2), ("book_impl", 0), ("order_impl", 1), ("order_impl", 2), ("order_impl", 0)):
+                        ("book_impl", 1), ("book_impl", 2), ("book_impl", 0), ("tail_impl", 1), ("tail_impl", 12), ("tail_impl", 0)):
         rx.set_option(name, value)
     rx.close()
 
@@ -1167,14 +1122,16 @@ def test_a_call_can_be_captured_in_a_hip_graph_and_replayed():
         assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
 
 
-@pytest.mark.parametrize("C,split", [(10240, 12), (10003, 8), (16384, 13)])
-def test_split_calls_are_complete_on_the_callers_stream_and_bit_exact(C, split):
-    """split_impl: a full-chain call on the wave-per-channel stage processes its channels in two parts -- FIR(A), FIR(B) on
-    the caller's stream, decoder + bookkeeping of A on the context's internal stream beside FIR(B) -- and joins the
-    internal stream before it returns the caller's.  Consecutive calls without any host synchronisation between them, the
-    outputs copied on the caller's stream right behind each call: every call against the oracle (a decoder of A that the
-    caller's stream did not wait for, or work-list counters shared by the two parts, would show here).  Also captured in
-    a HIP graph and replayed (the fork / join through events is a capturable pattern)."""
+@pytest.mark.parametrize("C,split", [(10240, 12), (10003, 8), (16384, 0), (16384, 14)])
+def test_gated_decoder_calls_are_complete_on_the_callers_stream_and_bit_exact(C, split):
+    """tail_impl (0 = the default: the first half): on the wave-per-channel stage the work list, decoder and bookkeeping of a
+    call's first channels run on the context's internal stream behind k_gate -- as soon as those channels' waves are finished,
+    while k_rx_chan6's last waves are still running -- and the caller's stream waits for the internal one before the call
+    returns it.  What those kernels read was stored through L2 by waves of a kernel that has not ended (OUT_AGENT stores,
+    m17_sync_wave.hip): a record, frame slot or count that stayed in a writer's cache would show here as a wrong or missing
+    payload.  Consecutive calls without any host synchronisation between them, the outputs copied on the caller's stream
+    right behind each call, every call against the oracle; also captured in a HIP graph and replayed (the gate's target is
+    the same for every call)."""
     torch = _torch()
     import m17_sdr_amd as m
     lengths = (16, 16, 20, 16)
@@ -1185,7 +1142,7 @@ def test_split_calls_are_complete_on_the_callers_stream_and_bit_exact(C, split):
     iq_host = iq_all.cpu().numpy()
     rx = m.Receiver(C, max(lengths))
     rx.set_option("fir_impl", 4)
-    rx.set_option("split_impl", split)
+    rx.set_option("tail_impl", split)
     s = torch.cuda.Stream()
     got = []
     at = 0
@@ -1194,6 +1151,7 @@ def test_split_calls_are_complete_on_the_callers_stream_and_bit_exact(C, split):
             part = iq_all[:, at:at + nblk].contiguous()
             at += nblk
             out = rx.rx_blocks(part, 1, rx.alloc_outputs(nblk, want_syms=True))
+            assert rx.last_path()["gated"] == (((C * (split or 8)) // 16) & ~31), rx.last_path()
             got.append({k: out[k].clone() for k in ("recs", "counts", "syms", "nsyms")})      # on s, behind the call: no host sync
     torch.cuda.synchronize()
     och = oracle.Channels(C)
@@ -1221,7 +1179,7 @@ def test_split_calls_are_complete_on_the_callers_stream_and_bit_exact(C, split):
         def run(graph):
             r2 = m.Receiver(C, 16)
             r2.set_option("fir_impl", 4)
-            r2.set_option("split_impl", split)
+            r2.set_option("tail_impl", split)
             out = r2.alloc_outputs(16)
             stage = torch.empty_like(slabs[0])
             res = []

@@ -102,3 +102,26 @@ def test_modulator_literals_and_geometry():
     outv = np.zeros(368, np.float32)
     oracle.L().m17o_de_interleave(oracle.vp(soft), oracle.vp(outv), 368)
     np.testing.assert_array_equal(outv[perm], soft)
+
+
+def test_streaming_arithmetic_literals():
+    """The literals and control constants of the streaming DSP stages -- int16 scale, demapper offset and reference, the
+    discriminator's factor and /5 pick, the timing loop's thresholds and initial state, the framer's vote / variance gates,
+    N_FERROR, the frame clock after a sync, the Viterbi start metric and traceback mask, the Golay error table's fill -- as
+    tests/golden/extract_ref_constants.py found them in the reference's source text, each inside the statement that uses
+    it (file:line recorded per entry).  Oracle and product each hold them under ONE name per literal, used by their code
+    and returned by their getters: all three must agree, so a mistyped threshold on either side cannot hide behind the
+    other.  (It pins constants, not arithmetic: parity of the streaming stages stays "unpinned")"""
+    ref = REF["rx_literals"]
+    want = np.array(ref["value"], np.float64)
+    assert len(ref["order"]) == len(want) == 24 and all(k in ref["source"] for k in ref["order"])
+    np.testing.assert_array_equal(_oracle("rx_literals", np.float64, 24), want)
+    np.testing.assert_array_equal(_product("rx_literals", np.float64, 24), want)
+    named = dict(zip(ref["order"], want))
+    # the values the verdicts of rounds 1-5 read out of the reference by eye
+    assert named["s16_scale"] == 0.00003 and named["demap_offset"] == 0.6666 and named["thresh_unlocked"] == 10 and \
+        named["thresh_locked"] == 80 and named["index_init"] == 10 and named["n_ferror"] == 5 and named["golay_fill_end"] == 0xFFF
+    # the oracle's freshly reset channel starts from the extracted initial state
+    ch = oracle.Channels(1)
+    assert (int(ch.field("m_clk")[0]), int(ch.field("m_thr")[0]), int(ch.field("m_index")[0])) == \
+        (int(named["clk_init"]), int(named["thr_init"]), int(named["index_init"]))
