@@ -162,11 +162,6 @@ int m17gpu_golay_decode(m17gpu_ctx *ctx, const uint32_t *d_words, uint16_t *d_ou
  *                            one workgroup, the front end sixteen blocks ahead of the timing loop (k_sync_frame_duo<1>;
  *                            calls of up to eight blocks start on four-row tiles; falls back to 1 where the two-wave
  *                            timing kernel does not apply)
- *   "tail_impl"          full-chain calls on the wave-per-channel stage (fir 4): 0 = by measurement (default: 8), 1 = off,
- *                            k = 2..15: the work list, decoder and bookkeeping of the first k / 16 of the channels run on an
- *                            internal stream of the context behind a gate (k_gate) that opens when those channels' waves are
- *                            finished -- in the tail of k_rx_chan6, whose last waves leave a third of the chip idle -- and the
- *                            caller's stream waits for that stream before the call returns it
  *   "slot_impl"          how the framer hands a stream frame to the decoder: 1 = its 192 symbols (768 B; the decoder stages
  *                            them in LDS), 2 = regrouped into the order the decoder reads (1,600 B), 0 = by path (default):
  *                            1 behind the wave-per-channel FIR stage, 2 behind front end + timing kernel
@@ -216,7 +211,7 @@ int m17gpu_get_lock(m17gpu_ctx *ctx, uint8_t *h_lock /* [C] */);
 int m17gpu_get_timing_state(m17gpu_ctx *ctx, int32_t *h_int, float *h_flt);
 /* What the last m17gpu_rx_blocks call ran (the library picks its kernels by call): h_path[0] = FIR stage ("fir_impl"
  * value: 1, 4, 5), [1] = stream frame slots plain (1) or regrouped (0), [2] = bookkeeping kernel (1 wave / 2 lane per
- * channel, 0 = none: mode 0), [3] = channels whose decoder ran behind the gate ("tail_impl"; 0 = none). */
+ * channel, 0 = none: mode 0), [3] = 0 (reserved). */
 int m17gpu_get_last_path(const m17gpu_ctx *ctx, int h_path[4]);
 /* host copies of the uploaded tables, for inspection / tests */
 int m17gpu_get_taps(float *h_mf /* [40][31] */, float *h_md /* [40][31] */);

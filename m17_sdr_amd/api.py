@@ -335,11 +335,10 @@ class Receiver:
                 "m_frame_errors": ai[:, 5], "sum": af[:, 0].copy(), "dif": af[:, 1].copy(), "z": af[:, 2:6].copy(), "m_buff": buff}
 
     def last_path(self):
-        """What the last rx_blocks call ran: dict(fir=1|4|5, plain_slots, book=0|1|2, gated=channels whose decoder ran
-        behind the gate) (m17gpu_get_last_path)."""
+        """What the last rx_blocks call ran: dict(fir=1|4|5, plain_slots, book=0|1|2) (m17gpu_get_last_path)."""
         a = (C.c_int * 4)()
         _check(lib().m17gpu_get_last_path(self._ctx, a), "m17gpu_get_last_path")
-        return {"fir": a[0], "plain_slots": a[1], "book": a[2], "gated": a[3]}
+        return {"fir": a[0], "plain_slots": a[1], "book": a[2]}
 
     def lock(self):
         a = np.zeros((self.C,), np.uint8)

@@ -1,8 +1,7 @@
 // m17_fused.hip -- k_rx_chan6: the whole FIR stage of ONE CHANNEL IN ONE WAVE -- int16 IQ -> limiter -> FM discriminator ->
 // /5 -> DC removal (dsp_short_to_float m17_dsp.cpp:136-141, dsp_limit :412-419, dsp_arctan_disc2 :194-222), then the
 // polyphase timing loop (m17_rx_sync_samples m17_rx_sync.cpp:77-99), the sync correlator and the framer
-// (m17_rx_frame.cpp:47-177) -- and k_gate, behind which the decoder of the launch's first channels starts while its last
-// waves are still running.
+// (m17_rx_frame.cpp:47-177).
 //
 // Why one wave runs both phases (DESIGN.md sections 5 and 6): as two kernels the stage's two halves sit on different roofs
 // -- the front end on vector-memory throughput with most of its issue slots idle, the timing loop on issue / dependency
@@ -47,24 +46,24 @@ __device__ unsigned long long g_rc_stamps[16384][4];          // per channel: ti
 // half the registers (sync_wave_channel<1>) -- six waves per SIMD.  Measured: the stage is bound by the
 // vector ALU (~76 % busy) and by its traffic past L2 (4.7-5.1 TB/s), not by what more waves would cover.
 //
-// The tail and the gate (round 6).  16,384 waves over 6,144 wave slots are 2.67 generations: for the last third of the launch's
-// span the slots empty, and its last waves run alone on their SIMDs, latency-bound (residency table in
-// profiles/r05_stamps_rx_chan.txt; neither the dispatch order nor a split of the launch shortens that tail:
-// profiles/r06_dispatch_order_ab.txt, r06_split_call_ab.txt).  The decoder behind it is bound by the vector ALU and needs
-// nothing of the channels still running: so every wave that has finished a channel below `gate_n` -- its records, frame
-// slots and record count written through L2 (OUT_AGENT stores) and complete (s_waitcnt vmcnt(0)) -- adds one to `done`
-// at agent scope, and k_gate, one wave on the context's internal stream, returns when all gate_n have: the work-list,
-// decoder and bookkeeping kernels of those channels are ordered behind it and run in the launch's tail.
+// The tail (round 6).  16,384 waves over 6,144 wave slots are 2.67 generations: for the last third of the launch's span the
+// slots empty and its last waves run alone on their SIMDs, latency-bound (residency: profiles/r05_stamps_rx_chan.txt).
+// Three ways to shorten or fill it were built, all bit-exact, none faster, none kept (the implementations are commits
+// 4cfa6db and 6dc0fdc): dispatching the channels by the work their last call took, heaviest first (a wave's lifetime is set
+// by WHEN it runs, not by what it has to do: -1.4 %, profiles/r06_dispatch_order_ab.txt); the call split into two channel
+// parts with the decoder of the first on an internal stream beside the FIR stage of the second (+4...8 %:
+// profiles/r06_split_call_ab.txt); and the decoder of the launch's first channels started behind a gate kernel while the
+// last waves still run, the framer's outputs written through L2 for it (the write-through stores alone cost 8 %:
+// profiles/r06_gated_decoder_ab.txt).
 constexpr int RC6_LDS = 6144;                  // per wave: the two 2,304-byte tiles / the timing loop's WvChan (4 KB); a multiple of 2 KB (ring alignment)
 static_assert(RC6_LDS >= 2 * FL_TILE_BYTES && RC6_LDS >= (int)sizeof(WvChan) && RC6_LDS % 2048 == 0, "k_rx_chan6 LDS layout");
 // TAIL: the call's block count is no multiple of sixteen (the host picks the build): only then is there a last group whose
 // tiles the workgroup's channels share, with its barrier.
-template <int TAIL, int AG>
+template <int TAIL>
 __global__ __launch_bounds__(64 * RC_WAVES, 6)
 void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float *__restrict__ disc, float *__restrict__ offs,
                 int C, int nblk, int mode, m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
-                float *__restrict__ syms, int32_t *__restrict__ nsyms, float *__restrict__ fsym,
-                uint32_t *__restrict__ done, int gate_n)   // channels [0, gate_n) report to *done when they are finished (null: nobody waits)
+                float *__restrict__ syms, int32_t *__restrict__ nsyms, float *__restrict__ fsym)
 {
     __shared__ __attribute__((aligned(4096))) unsigned char lds[RC_WAVES][RC6_LDS];
     const int wave = uni((int)(threadIdx.x >> 6));
@@ -110,8 +109,8 @@ void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float 
         { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_fe += now - t_last; t_last = now; }
 #endif
         if (live) {
-            sync_wave_channel<1, 1, AG>(dw, ow, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, bc,
-                                       chan, wc, wave, rc_lane());
+            sync_wave_channel<1, 1>(dw, ow, st, C, nblk, mode, -1, recs, rec_cap, counts, syms, nsyms, fsym, b0, bc,
+                                    chan, wc, wave, rc_lane());
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // channel state out before the next group reads it
             wave_lds_sync();
         }
@@ -119,36 +118,11 @@ void k_rx_chan6(const uint4 *__restrict__ iq, ChanState *__restrict__ st, float 
         { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_tm += now - t_last; t_last = now; }
 #endif
     }
-    // the channel is finished: everything the decoder and the bookkeeping kernel read of it went through L2 (OUT_AGENT) and is
-    // complete (the wait above); one count per channel below gate_n
-    if (AG && done && live && chan < gate_n && lane_id() == 0)
-        __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef M17_STAMPS
     if (live && chan < 16384 && lane_id() == 0) {
         g_rc_stamps[chan][0] = t_fe; g_rc_stamps[chan][1] = t_tm; g_rc_stamps[chan][2] = rt_in; g_rc_stamps[chan][3] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-}
-
-// k_gate: one wave that returns when `n` channels have reported to *done (k_rx_chan6), taking them off the counter again
-// -- the target is the same for every call, so a captured graph replays correctly.  It polls at agent scope with the wave
-// asleep in between; kernels enqueued behind it on its stream start with the usual cache invalidation and read what
-// those channels wrote.  A counter that does not arrive within ~4 s of the chip's 100 MHz clock (it always does: the waves
-// it waits for are running, or queued behind nothing that waits) ends the wait with err[0] = 1, which every state getter reports.
-__global__ __launch_bounds__(64)
-void k_gate(uint32_t *__restrict__ done, uint32_t n, uint32_t *__restrict__ err)
-{
-    if (threadIdx.x != 0) return;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
-        __builtin_amdgcn_s_sleep(32);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {
-            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-    }
-    __hip_atomic_fetch_sub(done, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 } // namespace m17dev

@@ -261,8 +261,6 @@ __device__ __forceinline__ int hunt_pass(int pos, int n, int gl, Ld ld, SyncResu
 }
 
 // one record: five words from scalars, eleven zero words, lanes 0..15
-// AG: stored through L2 at agent scope (sync_wave_channel's OUT_AGENT)
-template <int AG = 0>
 __device__ __forceinline__ void emit_record_wave(m17gpu_rec_dev *crecs, int rec_cap, int idx, int gl,
                                                  uint32_t w0, uint32_t w1, float var, uint32_t block, uint32_t sympos)
 {
@@ -271,10 +269,7 @@ __device__ __forceinline__ void emit_record_wave(m17gpu_rec_dev *crecs, int rec_
     asm("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\t"
         "v_writelane_b32 %0, %4, 3\n\tv_writelane_b32 %0, %5, 4"
         : "+v"(v) : "s"(uni((int)w0)), "s"(uni((int)w1)), "s"(uni(__float_as_int(var))), "s"(uni((int)block)), "s"(uni((int)sympos)));
-    if (gl < 16) {
-        if constexpr (AG) __hip_atomic_store(&reinterpret_cast<int *>(&crecs[idx])[gl], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else reinterpret_cast<int *>(&crecs[idx])[gl] = v;
-    }
+    if (gl < 16) reinterpret_cast<int *>(&crecs[idx])[gl] = v;
 }
 
 

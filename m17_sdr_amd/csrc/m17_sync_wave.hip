@@ -92,23 +92,11 @@ __device__ __forceinline__ void ring_st(int i, unsigned hb, float v) { *(lds_f *
 
 // A completed frame, in place in the ring from element fs, into its slot of the decoder's workspace (layout:
 // m17_dev.h kSlotFloats; store_frame_slot, m17_sync_common.hip).  rgw = the lane's packed regroup bytes.
-// AG: stored through L2 at agent scope, one dword per instruction (sync_wave_channel's OUT_AGENT).
-template <int AG> __device__ __forceinline__ void out_st(float *p, float v)
-{
-    if constexpr (AG) __hip_atomic_store(reinterpret_cast<uint32_t *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-template <int AG> __device__ __forceinline__ void out_st4(float *p, const float4 v)
-{
-    if constexpr (AG) { out_st<1>(p, v.x); out_st<1>(p + 1, v.y); out_st<1>(p + 2, v.z); out_st<1>(p + 3, v.w); }
-    else *reinterpret_cast<float4 *>(p) = v;
-}
-template <int AG = 0>
 __device__ __forceinline__ void store_frame_slot_wave(float *__restrict__ fd, int type, int gl, const uint32_t (&rgw)[2],
                                                       int fs, unsigned hb)
 {
     if (type == 2) {
-        if (gl < 8) out_st<AG>(&fd[gl], ring_ld(fs + gl, hb));
+        if (gl < 8) fd[gl] = ring_ld(fs + gl, hb);
         float4 t[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -117,12 +105,12 @@ __device__ __forceinline__ void store_frame_slot_wave(float *__restrict__ fd, in
             for (int c = 0; c < 4; ++c) e[c] = ring_ld(fs + 8 + (int)((rgw[r] >> (8 * c)) & 0xFFu), hb);
             t[r] = make_float4(e[0], e[1], e[2], e[3]);
         }
-        out_st4<AG>(fd + 8 + 4 * gl, t[0]);
-        if (gl < kRegroup / 4 - 64) out_st4<AG>(fd + 8 + 4 * (gl + 64), t[1]);
+        *reinterpret_cast<float4 *>(fd + 8 + 4 * gl) = t[0];
+        if (gl < kRegroup / 4 - 64) *reinterpret_cast<float4 *>(fd + 8 + 4 * (gl + 64)) = t[1];
     } else if (gl < kFrameSyms / 4) {
         const float4 t = make_float4(ring_ld(fs + 4 * gl, hb), ring_ld(fs + 4 * gl + 1, hb), ring_ld(fs + 4 * gl + 2, hb),
                                      ring_ld(fs + 4 * gl + 3, hb));
-        out_st4<AG>(fd + 4 * gl, t);
+        *reinterpret_cast<float4 *>(fd + 4 * gl) = t;
     }
 }
 
@@ -244,7 +232,6 @@ struct WvOut {
     float *fsym_chan;                          // this channel's frame slots [rec_cap][kSlotFloats]
     int mode, ext_lock;
 };
-template <int AG = 0>
 __device__ __forceinline__ void wv_framer_block(WvCtl &t, WvOut &o, const int n, const int b, const unsigned hb, const int gl,
                                                 const RegroupLane<64> &rg, unsigned *wst)
 {
@@ -282,10 +269,10 @@ __device__ __forceinline__ void wv_framer_block(WvCtl &t, WvOut &o, const int n,
                 }
                 if (parse && (o.mode & 1)) flags |= M17_F_PARSED;
                 const uint32_t w0 = (uint32_t)r.type | ((uint32_t)r.votes << 8) | ((uint32_t)(t.ferr & 0xFF) << 24);
-                emit_record_wave<AG>(o.crecs, o.rec_cap, t.nrec, gl, w0, flags, r.variance, t.block_count, (uint32_t)(pos - 1));
+                emit_record_wave(o.crecs, o.rec_cap, t.nrec, gl, w0, flags, r.variance, t.block_count, (uint32_t)(pos - 1));
                 if ((flags & M17_F_PARSED) && t.nrec < o.rec_cap && r.type >= 1 && r.type <= 3) {
                     float *fd = o.fsym_chan + (size_t)t.nrec * kSlotFloats;
-                    store_frame_slot_wave<AG>(fd, (o.mode & 16) ? 1 : r.type, gl, rg.w, fs, hb);     // mode bit 4 (slot_impl 1): every frame as its 192 symbols
+                    store_frame_slot_wave(fd, (o.mode & 16) ? 1 : r.type, gl, rg.w, fs, hb);     // mode bit 4 (slot_impl 1): every frame as its 192 symbols
                 }
                 t.nrec++;
                 if (unlock) {
@@ -304,7 +291,7 @@ __device__ __forceinline__ void wv_framer_block(WvCtl &t, WvOut &o, const int n,
                 const int js = pos + l;
                 // copy_sync(); m_fclk = 8; lock; m17_aos(): the window already is the head of the frame
                 t.fclk = M17_LIT_FCLK_AFTER_SYNC; t.ferr = 0; t.flock = 1;
-                emit_record_wave<AG>(o.crecs, o.rec_cap, t.nrec, gl, (uint32_t)r.type | ((uint32_t)r.votes << 8), M17_F_AOS, r.variance,
+                emit_record_wave(o.crecs, o.rec_cap, t.nrec, gl, (uint32_t)r.type | ((uint32_t)r.votes << 8), M17_F_AOS, r.variance,
                                  t.block_count, (uint32_t)js);
                 t.nrec++;
                 pos = js + 1;
@@ -332,7 +319,6 @@ __device__ __forceinline__ void wv_load_state(WvCtl &t, const ChanState &cs, con
     if (t.flock) { for (int q = gl; q < t.fclk; q += 64) ring_st(t.hp - t.fclk + q, hb, cs.fsym[q]); }
     else if (gl < 8) ring_st(t.hp - 8 + gl, hb, cs.sync[gl]);
 }
-template <int AG = 0>
 __device__ __forceinline__ void wv_store_state(const WvCtl &t, ChanState &cs, int32_t *counts, int chan, int ext_lock, unsigned hb, int gl)
 {
     const float sum_out = readlane_f(t.cs_, t.clane), dif_out = readlane_f(t.cd_, t.clane);
@@ -340,10 +326,7 @@ __device__ __forceinline__ void wv_store_state(const WvCtl &t, ChanState &cs, in
         cs.clk = t.clk; cs.thr = t.thr; cs.index = t.index; cs.sum = sum_out; cs.dif = dif_out; cs.buff[0] = 0.0f;
         if (ext_lock < 0) {
             cs.flock = t.flock; cs.fclk = t.fclk; cs.ferr = t.ferr; cs.block_count = t.block_count; cs.sym_total = t.sym_total;
-            if (counts) {
-                if constexpr (AG) __hip_atomic_store(&counts[chan], t.nrec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else counts[chan] = t.nrec;
-            }
+            if (counts) counts[chan] = t.nrec;
         }
     }
     if (ext_lock < 0) {
@@ -357,9 +340,7 @@ __device__ __forceinline__ void wv_store_state(const WvCtl &t, ChanState &cs, in
 // OFFS_AGENT: the block offsets are read past the CU's caches (agent scope) -- for a caller whose rows were written in
 // this kernel by ANOTHER wave of the workgroup (k_rx_chan6's shared tiles): thirty-two offsets share a 128-byte line, and a
 // line this wave read for an earlier group must not be served again once a sibling has written the next group's part of it.
-// OUT_AGENT: what the decoder and the bookkeeping kernel read of the channel -- records, frame slots, the record count -- is
-// stored through L2 (agent scope), for a caller whose consumers start before this kernel has ended (k_rx_chan6 and k_gate).
-template <int HALF = 0, int OFFS_AGENT = 0, int OUT_AGENT = 0>
+template <int HALF = 0, int OFFS_AGENT = 0>
 __device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc, const float *__restrict__ offs,
                        ChanState *__restrict__ st, int C, int nblk, int mode, int ext_lock,
                        m17gpu_rec_dev *__restrict__ recs, int rec_cap, int32_t *__restrict__ counts,
@@ -434,7 +415,7 @@ __device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc
 #pragma unroll
             for (int r = 0; r < PF; ++r) pf[r] = __builtin_nontemporal_load(&nx[gl + LPC * r]);   // read once
         }
-        wv_framer_block<OUT_AGENT>(t, o, n, b, hb, gl, rg, wst);
+        wv_framer_block(t, o, n, b, hb, gl, rg, wst);
 
         // delay line: last 30 inputs; then the prefetched block moves in
         {
@@ -454,7 +435,7 @@ __device__ __forceinline__ void sync_wave_channel(const float *__restrict__ disc
     WSTAMP(5);
 #endif
     // ---- store state in the reference's layout
-    wv_store_state<OUT_AGENT>(t, cs, counts, chan, ext_lock, hb, gl);
+    wv_store_state(t, cs, counts, chan, ext_lock, hb, gl);
     if (gl < kTaps - 1) cs.buff[gl + 1] = my.x[gl];
 #ifdef M17_STAMPS
     // epilogue (state out, every store of the wave complete: what s_endpgm waits for), the wave's life on the chip-wide

@@ -66,15 +66,8 @@ struct m17gpu_ctx {
     int fir_impl = 0;                        // 0 = by call (fir_choice); 1 = front end + timing kernel; 4 = wave per channel over sixteen-row
                                              // tiles of its own blocks, rows through the workspace, six waves per SIMD (k_rx_chan6);
                                              // 5 = three waves per channel, the front end one of them (k_sync_frame_duo<1>, up to 1,024 channels)
-    int tail_impl = 0;                       // full-chain calls on the wave-per-channel stage: 0 = by measurement (tail_choice), 1 = off, 2..15 = the
-                                             // decoder and bookkeeping of the first tail_impl / 16 of the channels start behind k_gate, on the internal
-                                             // stream, as soon as those channels are finished -- in the tail of k_rx_chan6
-    hipStream_t s2 = nullptr;                // the internal stream (non-blocking, highest priority) and the events that fork it from and join it to the caller's
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    uint32_t *d_gate = nullptr;              // [0] channels finished (k_rx_chan6 adds, k_gate takes off), [1] a gate gave up waiting
-    bool gate_dirty = false;                 // a call got past the k_rx_chan6 launch but not to its k_gate: the counter is not zero
     bool nwork_dirty = false;                // a full-chain call got past k_worklist but not to the bookkeeping kernel that zeroes the counters
-    int last_path[4] = {0, 0, 0, 0};         // what the last m17gpu_rx_blocks call ran: FIR stage (fir_choice), plain slots, bookkeeping kernel, gated channels
+    int last_path[4] = {0, 0, 0, 0};         // what the last m17gpu_rx_blocks call ran: FIR stage (fir_choice), plain slots, bookkeeping kernel, (reserved)
     std::vector<hipEvent_t> ev_pool;         // 7 events per profiled call: 5 stage marks + call start / end
     std::vector<int> ev_mode;                // mode of each profiled call
 };
@@ -282,27 +275,15 @@ int fir_choice(const m17gpu_ctx *ctx, int nblk)
     // profiles/r05_channel_count_crossover.txt)
     return (ctx->C >= 10000 && nblk >= 12) ? 4 : 1;
 }
-// Channels whose decoder starts behind the gate (0 = none: one decoder launch behind the whole FIR stage).  k_rx_chan6 ends in a
-// tail (2.67 generations of equal waves; its last waves run alone on their SIMDs, latency-bound) in which a third of the
-// chip's wave slots stand empty; the decoder of the channels that are finished by then fits there.  Whole lines of the
-// per-channel count array (32 channels) so that no line is written through L2 by one part and cached by the other.
-int tail_choice(const m17gpu_ctx *ctx, int nblk, int fir, bool full)
-{
-    if (!full || fir != 4 || ctx->tail_impl == 1 || !ctx->s2 || ctx->d_net) return 0;
-    const int k = ctx->tail_impl ? ctx->tail_impl : 8;
-    const int a = (int)((long long)ctx->C * k / 16) & ~31;
-    return (a >= 32 && ctx->C - a >= 32) ? a : 0;
-}
-// the wave-per-channel FIR stage (k_rx_chan6); channels [0, gate_n) report to the context's gate counter
+// the wave-per-channel FIR stage (k_rx_chan6)
 int launch_fused(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode, m17gpu_rec *d_recs, int rec_cap,
-                 int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st, int gate_n)
+                 int32_t *d_counts, float *d_syms, int32_t *d_nsyms, hipStream_t st)
 {
     mode |= plain_slots(ctx, nblk) ? 16 : 0;                         // bit 4: plain frame slots
-    auto kern = gate_n ? ((nblk % 16) ? k_rx_chan6<1, 1> : k_rx_chan6<0, 1>) : ((nblk % 16) ? k_rx_chan6<1, 0> : k_rx_chan6<0, 0>);
-    hipLaunchKernelGGL(kern, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
+    hipLaunchKernelGGL((nblk % 16) ? k_rx_chan6<1> : k_rx_chan6<0>, dim3(cdiv(ctx->C, RC_WAVES)), dim3(64 * RC_WAVES), 0, st,
                        reinterpret_cast<const uint4 *>(d_iq), ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->C, nblk, mode,
                        reinterpret_cast<m17gpu_rec_dev *>(d_recs), d_recs ? rec_cap : 0, d_counts ? d_counts : ctx->d_counts,
-                       d_syms, d_nsyms, ctx->d_fsym, gate_n ? ctx->d_gate : nullptr, gate_n);
+                       d_syms, d_nsyms, ctx->d_fsym);
     HIPCHK(hipGetLastError());
     return M17GPU_OK;
 }
@@ -395,18 +376,9 @@ int m17gpu_create(m17gpu_ctx **out, int n_channels, int max_blocks, int device)
     ALLOC(ctx->d_fsym, sizeof(float) * (size_t)n_channels * ctx->rec_cap_max * kSlotFloats);
     ALLOC(ctx->d_work, sizeof(int32_t) * 3 * (size_t)n_channels * ctx->rec_cap_max);   // one list per frame type (decode_impl 2)
     ALLOC(ctx->d_nwork, sizeof(int32_t) * 8);
-    ALLOC(ctx->d_gate, sizeof(uint32_t) * 2);
     ALLOC(ctx->d_counts, sizeof(int32_t) * (size_t)n_channels);
     ALLOC(ctx->d_dec_hist, sizeof(uint32_t) * 32 * (size_t)n_channels);
 #undef ALLOC
-    {
-        int lo = 0, hi = 0;
-        hipError_t e_ = hipDeviceGetStreamPriorityRange(&lo, &hi);                  // (least, greatest): numerically hi <= lo
-        if (e_ == hipSuccess) e_ = hipStreamCreateWithPriority(&ctx->s2, hipStreamNonBlocking, hi);
-        if (e_ == hipSuccess) e_ = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
-        if (e_ == hipSuccess) e_ = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
-        if (e_ != hipSuccess) { m17gpu_destroy(ctx); return fail(M17GPU_ERR_HIP, std::string("m17gpu_create: internal stream: ") + hipGetErrorString(e_)); }
-    }
     rc = m17gpu_reset(ctx, nullptr);
     if (rc != M17GPU_OK) { m17gpu_destroy(ctx); return rc; }
     {
@@ -425,13 +397,9 @@ void m17gpu_destroy(m17gpu_ctx *ctx)
     if (!ctx) return;
     DeviceScope dev_scope_(ctx->device);
     void *bufs[] = {ctx->d_state, ctx->d_disc, ctx->d_offs, ctx->d_fsym, ctx->d_work,
-                    ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis, ctx->d_dec_hist, ctx->d_flags,
-                    ctx->d_gate};
+                    ctx->d_nwork, ctx->d_counts, ctx->d_genc, ctx->d_gerr, ctx->d_crc_basis, ctx->d_dec_hist, ctx->d_flags};
     for (void *p : bufs) (void)hipFree(p);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    if (ctx->s2) { (void)hipStreamSynchronize(ctx->s2); (void)hipStreamDestroy(ctx->s2); }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
 }
 
@@ -444,8 +412,7 @@ int m17gpu_reset(m17gpu_ctx *ctx, void *stream)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(ctx->d_dec_hist, 0, sizeof(uint32_t) * 32 * (size_t)ctx->C, S(stream)));
     HIPCHK(hipMemsetAsync(ctx->d_nwork, 0, sizeof(int32_t) * 8, S(stream)));
-    HIPCHK(hipMemsetAsync(ctx->d_gate, 0, sizeof(uint32_t) * 2, S(stream)));
-    ctx->nwork_dirty = false; ctx->gate_dirty = false;
+    ctx->nwork_dirty = false;
     return M17GPU_OK;
 }
 
@@ -477,8 +444,7 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
     }
     const int fir = fir_choice(ctx, nblk);
     ctx->last_path[0] = fir; ctx->last_path[1] = plain_slots(ctx, nblk) ? 1 : 0; ctx->last_path[2] = 0;
-    const int gate_n = tail_choice(ctx, nblk, fir, full);
-    ctx->last_path[3] = gate_n;
+    ctx->last_path[3] = 0;
     hipEvent_t *ev = nullptr;
     if (ctx->profiling && ctx->ev_mode.size() < 512) {
         const size_t base = ctx->ev_pool.size();
@@ -512,13 +478,7 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
             MARK(2);
         } else if (fir == 4) {
             MARK(1);                             // no separate front end: stage 0 reads as zero, stage 1 is the wave-per-channel kernel
-            if (gate_n) {
-                // the gate counter is zero here (k_gate takes off what it waited for) unless a call failed between its FIR launch and its gate
-                if (ctx->gate_dirty) HIPCHK(hipMemsetAsync(ctx->d_gate, 0, sizeof(uint32_t), st));
-                HIPCHK(hipEventRecord(ctx->ev_fork, st));
-                ctx->gate_dirty = true;
-            }
-            if ((rc = launch_fused(ctx, d_iq, nblk, mode, d_recs, rec_cap, d_counts, d_syms, d_nsyms, st, gate_n)) != M17GPU_OK) return rc;
+            if ((rc = launch_fused(ctx, d_iq, nblk, mode, d_recs, rec_cap, d_counts, d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
             MARK(2);
         } else {
             if ((rc = launch_frontend(ctx, d_iq, nblk, ctx->d_disc, ctx->d_offs, 1, st)) != M17GPU_OK) return rc;
@@ -527,22 +487,7 @@ int m17gpu_rx_blocks(m17gpu_ctx *ctx, const int16_t *d_iq, int nblk, int mode,
                                         d_syms, d_nsyms, st)) != M17GPU_OK) return rc;
             MARK(2);
         }
-        if (full && gate_n) {
-            // channels [0, gate_n): work list, decoder and bookkeeping on the internal stream, behind the gate -- they start
-            // while k_rx_chan6's last waves are still running; the rest on the caller's stream behind the kernel, which then waits
-            // for the internal stream: everything of the call is complete on `stream`
-            const bool plain = plain_slots(ctx, nblk);
-            HIPCHK(hipStreamWaitEvent(ctx->s2, ctx->ev_fork, 0));
-            hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, ctx->s2, ctx->d_gate, (uint32_t)gate_n, ctx->d_gate + 1);
-            HIPCHK(hipGetLastError());
-            ctx->gate_dirty = false;
-            if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, ctx->s2, 0, gate_n, 0, nullptr, plain)) != M17GPU_OK) return rc;
-            HIPCHK(hipEventRecord(ctx->ev_join, ctx->s2));
-            if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, st, gate_n, ctx->C - gate_n, 1, ev ? ev[3] : nullptr, plain)) != M17GPU_OK) return rc;
-            HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
-            ctx->nwork_dirty = false;
-            MARK(4);
-        } else if (full) {
+        if (full) {
             if ((rc = launch_decode(ctx, d_recs, rec_cap, d_counts, st, 0, ctx->C, 0, ev ? ev[3] : nullptr, plain_slots(ctx, nblk))) != M17GPU_OK) return rc;
             ctx->nwork_dirty = false;
             MARK(4);
@@ -652,19 +597,9 @@ int m17gpu_set_option(m17gpu_ctx *ctx, const char *name, int value)
     if (!std::strcmp(name, "sync_impl")) { if (value != 0 && value != 6 && value != 8) return bad(); ctx->sync_impl = value; }
     else if (!std::strcmp(name, "fe_impl")) { if (value != 0 && (value < 2 || value > 4)) return bad(); ctx->fe_impl = value; }
     else if (!std::strcmp(name, "fir_impl")) { if (value != 0 && value != 1 && value != 4 && value != 5) return bad(); ctx->fir_impl = value; }
-    else if (!std::strcmp(name, "tail_impl")) { if (value < 0 || value > 15) return bad(); ctx->tail_impl = value; }
-    else if (!std::strcmp(name, "tail_prio")) {            // EXPERIMENT: priority of the internal stream, 0 = lowest, 1 = highest
-        if (value != 0 && value != 1) return bad();
-        ON_CTX_DEVICE(ctx);
-        int lo = 0, hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        if (ctx->s2) { HIPCHK(hipStreamSynchronize(ctx->s2)); HIPCHK(hipStreamDestroy(ctx->s2)); ctx->s2 = nullptr; }
-        HIPCHK(hipStreamCreateWithPriority(&ctx->s2, hipStreamNonBlocking, value ? hi : lo));
-    }
     else if (!std::strcmp(name, "afc")) { if (value != 0 && value != 1) return bad(); ctx->afc = value; }
     else if (!std::strcmp(name, "slot_impl")) { if (value < 0 || value > 2) return bad(); ctx->slot_impl = value; }
     else if (!std::strcmp(name, "book_impl")) { if (value < 0 || value > 2) return bad(); ctx->book_impl = value; }
-
 #ifdef M17_STAMPS
     else if (!std::strcmp(name, "fe_debug")) { ctx->fe_debug = value; }      // instrumented build only: WRONG results
 #endif
@@ -1243,9 +1178,6 @@ static int fetch_state(m17gpu_ctx *ctx, std::vector<ChanState> &h)
     h.resize((size_t)ctx->C);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(h.data(), ctx->d_state, sizeof(ChanState) * (size_t)ctx->C, hipMemcpyDeviceToHost));
-    uint32_t gate[2] = {0, 0};
-    HIPCHK(hipMemcpy(gate, ctx->d_gate, sizeof gate, hipMemcpyDeviceToHost));
-    if (gate[1]) return fail(M17GPU_ERR_HIP, "a decoder gate gave up waiting for its channels (k_gate): the results of that call are incomplete");
     return M17GPU_OK;
 }
 

@@ -1,4 +1,4 @@
-"""k_rx_chan6 (fir_impl 4; M17_TAIL = tail_impl), instrumented build (make stamps): per-wave ticks in the front-end tiles and in the timing phases,
+"""k_rx_chan6 (fir_impl 4), instrumented build (make stamps): per-wave ticks in the front-end tiles and in the timing phases,
 wave lifetimes and residency.   python scripts/exp_stamps_rc.py [channels] [blocks] [mode]"""
 import sys, os, ctypes as C, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,6 @@ mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 T = 6
 rx = m.Receiver(Cn, nblk)
 rx.set_option("fir_impl", int(os.environ.get("M17_FIR_IMPL", "4")))
-rx.set_option("tail_impl", int(os.environ.get("M17_TAIL", "0")))
 big = rx.gen_batch(nblk * T)["iq"]
 slabs = torch.empty((T, Cn, nblk, 1920, 2), dtype=torch.int16, device=big.device)
 slabs.copy_(big.view(Cn, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4))

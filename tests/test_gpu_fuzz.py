@@ -4,7 +4,7 @@ tests and what each kernel's design makes risky; this one covers combinations no
 
 The default run is a FIXED list of trials -- M17_FUZZ_TRIALS (default 60) trials of sequence M17_FUZZ_SEED (default 5),
 trial k drawn from its own generator seeded (seed, k), plus two forced large-batch trials (the sizes at which the
-library picks k_rx_chan6 with its shared last tiles, the gated decoder and the lane-per-channel bookkeeping) --
+library picks k_rx_chan6 with its shared last tiles and the lane-per-channel bookkeeping) --
 so it is the same on every box whatever its speed, and a failure names the trial: M17_FUZZ_ONLY=k re-runs trial k alone.
 M17_FUZZ_SECONDS > 0 turns it into a time-bounded experiment that keeps drawing past the fixed list
 (profiles/r05_fuzz_parity.txt, r06_fuzz_parity.txt); a safety cap of 300 s ends a default run that got too slow."""
@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 _CHANNELS = [1, 2, 3, 7, 17, 63, 64, 65, 100, 257, 640, 1000, 1024, 1025, 2500]
 _OPTION_VALUES = {"fe_impl": [0, 2, 3, 4], "fir_impl": [0, 1, 4, 5], "sync_impl": [0, 6, 8],
-                  "slot_impl": [0, 1, 2], "book_impl": [0, 1, 2], "tail_impl": [0, 1, 5, 12]}
+                  "slot_impl": [0, 1, 2], "book_impl": [0, 1, 2]}
 _FORCED = [dict(C=10003, nblk=14, mode=1, ebn0=9.0, nsf=5, packet_mode=0, calls=2, seed=0x4D313761, options={}),
            dict(C=12001, nblk=33, mode=0, ebn0=6.0, nsf=11, packet_mode=0, calls=1, seed=0x4D313762, options={"book_impl": 2})]
 

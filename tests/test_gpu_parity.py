@@ -236,7 +236,7 @@ def test_exact_arithmetic_selftest():
 
 
 @pytest.mark.parametrize("options", [
-    {"sync_impl": 8}, {"fe_impl": 3, "fir_impl": 1}, {"fe_impl": 4, "fir_impl": 1}, {"fir_impl": 1}, {"fir_impl": 4}, {"fir_impl": 4, "tail_impl": 1},
+    {"sync_impl": 8}, {"fe_impl": 3, "fir_impl": 1}, {"fe_impl": 4, "fir_impl": 1}, {"fir_impl": 1}, {"fir_impl": 4},
     {"fir_impl": 5}, {"fir_impl": 1, "sync_impl": 8}, {"slot_impl": 1}, {"slot_impl": 2}, {"book_impl": 1}, {"book_impl": 2},
     {"book_impl": 2, "fir_impl": 4}, {"slot_impl": 2, "fir_impl": 4}])
 def test_every_kernel_variant_is_bit_exact(options):
@@ -290,7 +290,7 @@ def test_config2_1024_channels_front_end_bit_exact():
 
 
 @pytest.mark.parametrize("ebn0,options,nblk", [(4.0, {}, 12), (8.0, {}, 12), (12.0, {}, 12), (10.0, {"fir_impl": 1}, 12), (10.0, {"fe_impl": 3, "fir_impl": 1}, 12),
-                                               (8.0, {}, 16), (200.0, {}, 16), (10.0, {"slot_impl": 2}, 16), (10.0, {"tail_impl": 1}, 16), (6.0, {"tail_impl": 13}, 16)])
+                                               (8.0, {}, 16), (200.0, {}, 16), (10.0, {"slot_impl": 2}, 16)])
 def test_config4_16384_channels_awgn_bit_exact(ebn0, options, nblk):
     """BASELINE configs[3] at its real size: 16,384 channels on one GPU, band-limited AWGN, signal from
     the device generator (every channel distinct), DEFAULT options -- so the kernels the bench runs at this size
@@ -684,14 +684,14 @@ def test_set_option_rejects_unknown_and_out_of_range_values():
     for name, value in (("fe_impl", 101), ("fe_impl", 107), ("fe_impl", -1), ("fe_impl", 5), ("fe_impl", 1), ("sync_impl", 2),
                         ("sync_impl", 5), ("sync_impl", 1), ("sync_impl", 4), ("sync_impl", 10), ("sync_impl", 7), ("sync_impl", 9),
                         ("fir_impl", 6), ("fir_impl", -1), ("fir_impl", 2), ("fir_impl", 3),         # removed in round 6: no longer reachable
-                        ("slot_impl", 3), ("book_impl", 3), ("tail_impl", 16), ("tail_impl", -1), ("order_impl", 1), ("split_impl", 8),
+                        ("slot_impl", 3), ("book_impl", 3), ("tail_impl", 8), ("order_impl", 1), ("split_impl", 8),      # round-6 experiments: not in the product
                         ("overlap_chunks", 2), ("fe_waves_per_cu", 8), ("lanes_per_channel", 16),
                         ("decode_impl", 0), ("no_such_option", 1)):
         with pytest.raises(RuntimeError):
             rx.set_option(name, value)
     for name, value in (("fe_impl", 0), ("fe_impl", 2), ("fe_impl", 3), ("fe_impl", 4), ("sync_impl", 0), ("sync_impl", 6), ("sync_impl", 8),
                         ("fir_impl", 0), ("fir_impl", 1), ("fir_impl", 4), ("fir_impl", 5), ("slot_impl", 1), ("slot_impl", 2), ("slot_impl", 0),
-                        ("book_impl", 1), ("book_impl", 2), ("book_impl", 0), ("tail_impl", 1), ("tail_impl", 12), ("tail_impl", 0)):
+                        ("book_impl", 1), ("book_impl", 2), ("book_impl", 0)):
         rx.set_option(name, value)
     rx.close()
 
@@ -1120,91 +1120,6 @@ def test_a_call_can_be_captured_in_a_hip_graph_and_replayed():
         assert torch.equal(a[1], b[1])
         assert torch.equal(a[0], b[0])
         assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
-
-
-@pytest.mark.parametrize("C,split", [(10240, 12), (10003, 8), (16384, 0), (16384, 14)])
-def test_gated_decoder_calls_are_complete_on_the_callers_stream_and_bit_exact(C, split):
-    """tail_impl (0 = the default: the first half): on the wave-per-channel stage the work list, decoder and bookkeeping of a
-    call's first channels run on the context's internal stream behind k_gate -- as soon as those channels' waves are finished,
-    while k_rx_chan6's last waves are still running -- and the caller's stream waits for the internal one before the call
-    returns it.  What those kernels read was stored through L2 by waves of a kernel that has not ended (OUT_AGENT stores,
-    m17_sync_wave.hip): a record, frame slot or count that stayed in a writer's cache would show here as a wrong or missing
-    payload.  Consecutive calls without any host synchronisation between them, the outputs copied on the caller's stream
-    right behind each call, every call against the oracle; also captured in a HIP graph and replayed (the gate's target is
-    the same for every call)."""
-    torch = _torch()
-    import m17_sdr_amd as m
-    lengths = (16, 16, 20, 16)
-    total = sum(lengths)
-    gen = m.Receiver(C, total)
-    iq_all = gen.gen_batch(total, n_stream_frames=9, ebn0_db=11.0, noise_cutoff_hz=6250.0)["iq"]
-    gen.close()
-    iq_host = iq_all.cpu().numpy()
-    rx = m.Receiver(C, max(lengths))
-    rx.set_option("fir_impl", 4)
-    rx.set_option("tail_impl", split)
-    s = torch.cuda.Stream()
-    got = []
-    at = 0
-    with torch.cuda.stream(s):
-        for nblk in lengths:
-            part = iq_all[:, at:at + nblk].contiguous()
-            at += nblk
-            out = rx.rx_blocks(part, 1, rx.alloc_outputs(nblk, want_syms=True))
-            assert rx.last_path()["gated"] == (((C * (split or 8)) // 16) & ~31), rx.last_path()
-            got.append({k: out[k].clone() for k in ("recs", "counts", "syms", "nsyms")})      # on s, behind the call: no host sync
-    torch.cuda.synchronize()
-    och = oracle.Channels(C)
-    at = 0
-    for nblk, out in zip(lengths, got):
-        ref = och.rx_blocks(np.ascontiguousarray(iq_host[:, at:at + nblk]), mode=1, nthreads=16, cap=rx.rec_cap_max)
-        at += nblk
-        counts = out["counts"].cpu().numpy()
-        np.testing.assert_array_equal(counts, ref["counts"])
-        np.testing.assert_array_equal(out["nsyms"].cpu().numpy(), ref["nsyms"])
-        np.testing.assert_array_equal(out["syms"].cpu().numpy().view(np.uint32), ref["syms"].view(np.uint32))
-        recs = out["recs"].cpu().numpy().view(oracle.REC_DTYPE).reshape(C, -1)
-        cap = recs.shape[1]
-        valid = np.arange(cap)[None, :] < counts[:, None]
-        g = recs.view(np.uint8).reshape(C, cap, 64)[valid]
-        r = ref["recs"].view(np.uint8).reshape(C, cap, 64)[valid]
-        bad = np.nonzero((g != r).any(axis=1))[0]
-        assert bad.size == 0, (nblk, bad[:5], g[bad[:1]], r[bad[:1]])
-    np.testing.assert_array_equal(rx.lsf(), och.field("m_lsf"))
-    np.testing.assert_array_equal(rx.counters(), och.field("counters"))
-    # ... and as a captured graph: replay on the next 16 blocks of a second stream of blocks against plain calls
-    if C == 10240:
-        slabs = [iq_all[:, 16 * k:16 * (k + 1)].contiguous() for k in range(3)]
-
-        def run(graph):
-            r2 = m.Receiver(C, 16)
-            r2.set_option("fir_impl", 4)
-            r2.set_option("tail_impl", split)
-            out = r2.alloc_outputs(16)
-            stage = torch.empty_like(slabs[0])
-            res = []
-            s2 = torch.cuda.Stream()
-            with torch.cuda.stream(s2):
-                stage.copy_(slabs[0]); r2.rx_blocks(stage, 1, out)
-                torch.cuda.synchronize()
-                g = None
-                if graph:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=s2):
-                        r2.rx_blocks(stage, 1, out)
-                for k in range(1, 3):
-                    stage.copy_(slabs[k])
-                    if g is not None:
-                        g.replay()
-                    else:
-                        r2.rx_blocks(stage, 1, out)
-                    torch.cuda.synchronize()
-                    res.append((out["recs"].clone(), out["counts"].clone()))
-            r2.close()
-            return res
-        for a, b in zip(run(False), run(True)):
-            assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
-    rx.close()
 
 
 def test_squelched_channels_do_not_slow_the_timing_stage():
