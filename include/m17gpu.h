@@ -281,8 +281,11 @@ int m17gpu_shard_gather_records(m17gpu_ctx *ctx, void *comm, int rank, int world
  *                               records per rank.  Three grouped exchanges: each rank's verdict on its own buffer with
  *                               its offset table to dst_rank; dst_rank's verdict over all of them (and over
  *                               packed_cap_all) back to every rank; then, only on "go", sum(counts) x 64 B per rank.
- *                               A buffer too small ANYWHERE makes EVERY rank return M17GPU_ERR_ARG with nothing moved
- *                               and no transfer left unmatched.  The sizes come from device memory, so the entry
+ *                               A buffer too small -- or missing, or a context of another channel count -- ANYWHERE makes
+ *                               EVERY rank return M17GPU_ERR_ARG with nothing moved and no transfer left unmatched: what is
+ *                               wrong on one rank travels as that rank's "no".  EVERY rank of the communicator must make the
+ *                               call, also one whose channel range is empty (world > channels: any context, NULL buffers,
+ *                               capacity 0); only a NULL ctx / comm or an impossible rank / world returns on that rank alone.  The sizes come from device memory, so the entry
  *                               synchronises `stream` (three times); it runs behind the step, beside nothing.
  *   m17gpu_shard_set_library    bind the fan-out entries to the library at `path` (ncclGroupStart / ncclGroupEnd /
  *                               ncclSend / ncclRecv with RCCL's signatures) instead of the process's RCCL; NULL = the

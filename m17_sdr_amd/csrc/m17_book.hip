@@ -457,7 +457,14 @@ void k_book_lanes(ChanState *__restrict__ st, m17gpu_rec_dev *__restrict__ recs,
                     }
                 }
             }
-            // packet frames (parse_packet, m17_rx_parse.cpp:34-51): the wave serves them one after the other
+            // packet frames (parse_packet, m17_rx_parse.cpp:34-51): the wave serves them one after the other.
+            // Coherence of the global packet buffer inside this wave: some lanes store bytes of c2s.packet, group_sync() (a
+            // workgroup-scope release + acquire: the stores have left the wave, vmcnt = 0) and other lanes load them back
+            // through the SAME CU's vector L1 -- which is write-through and shared by everything that runs on the CU, so a
+            // later load of this wave (or of a sibling in the workgroup) cannot be served a copy older than the store: what
+            // the AMDGPU memory model gives at workgroup scope outside tgsplit mode.  (The agent-scope loads of the DC
+            // offsets in sync_wave_channel<.., OFFS_AGENT> are stronger than that model requires; they are kept because
+            // they cost nothing measurable.  Data another CU wrote IN THIS KERNEL is never read here.)
             {
                 unsigned long long todo = __builtin_amdgcn_ballot_w64(parsed && type == 3);
                 while (todo) {

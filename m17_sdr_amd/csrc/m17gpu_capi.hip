@@ -821,13 +821,20 @@ int m17gpu_shard_gather_packed(m17gpu_ctx *ctx, void *comm, int rank, int world,
                                const m17gpu_rec *d_packed_mine, int packed_cap_mine, const int32_t *d_offsets_mine, int n_channels_total,
                                m17gpu_rec *d_packed_all, int packed_cap_all, int32_t *d_offsets_all, int32_t *h_totals, void *stream)
 {
-    if (!ctx || !comm || world <= 0 || rank < 0 || rank >= world || dst_rank < 0 || dst_rank >= world || n_channels_total <= 0 ||
-        !d_packed_mine || packed_cap_mine <= 0 || !d_offsets_mine ||
-        (rank == dst_rank && (!d_packed_all || !d_offsets_all || packed_cap_all <= 0)))
+    // Only what makes the exchange itself impossible returns here, on this rank alone (a caller's programming error: its
+    // peers then wait).  Everything else that is wrong on ONE rank -- no or too small a buffer, a context of another
+    // channel count -- becomes that rank's "no" in the verdict every rank takes part in, so that ALL ranks return
+    // M17GPU_ERR_ARG together and nothing is left unmatched.  Every rank of the communicator must make the call, also
+    // one whose channel range is empty (world > channels: it passes any context, no buffers and capacity 0).
+    if (!ctx || !comm || world <= 0 || rank < 0 || rank >= world || dst_rank < 0 || dst_rank >= world || n_channels_total <= 0)
         return fail(M17GPU_ERR_ARG, "m17gpu_shard_gather_packed: bad argument");
     int lo, hi;
     m17gpu_shard_range(rank, world, n_channels_total, &lo, &hi);
-    if (hi - lo != ctx->C) return fail(M17GPU_ERR_ARG, "m17gpu_shard_gather_packed: the context does not hold this rank's channel range");
+    const bool empty = hi == lo;
+    std::string why_local;
+    if (!empty && hi - lo != ctx->C) why_local = "the context does not hold this rank's channel range";
+    else if (!empty && (!d_packed_mine || packed_cap_mine <= 0 || !d_offsets_mine)) why_local = "no or an empty packed buffer on a rank that has channels";
+    else if (rank == dst_rank && (!d_packed_all || packed_cap_all <= 0)) why_local = "the gathering rank has no destination buffer";
     const RcclApi &R = rccl();
     if (!R.ok) return fail(M17GPU_ERR_HIP, "m17gpu_shard_gather_packed: no RCCL library in this process (librccl.so.1)");
     ON_CTX_DEVICE(ctx);
@@ -846,10 +853,30 @@ int m17gpu_shard_gather_packed(m17gpu_ctx *ctx, void *comm, int rank, int world,
         HIPCHK(hipMalloc(&ctx->d_flags, sizeof(int32_t) * (size_t)(world + 1)));
         ctx->n_flags = world + 1;
     }
+    // the gathering rank receives the peers' offset tables even when it will refuse: into a scratch table if it was given none
+    int32_t *offs_scratch = nullptr;
+    struct Scratch { int32_t *&p; ~Scratch() { (void)hipFree(p); } } scratch_{offs_scratch};
+    if (rank == dst_rank && !d_offsets_all) {
+        HIPCHK(hipMalloc(&offs_scratch, sizeof(int32_t) * ((size_t)n_channels_total + 1)));
+        d_offsets_all = offs_scratch;
+        if (why_local.empty()) why_local = "the gathering rank has no offset table";
+    }
+    const bool can_read = !empty && d_offsets_mine && hi - lo == ctx->C;
+    // ... and a peer that has channels but no table to send ("no" for that very reason) sends zeros of the right length: the
+    // gathering rank's receive is posted by channel range
+    int32_t *offs_dummy = nullptr;
+    Scratch dummy_{offs_dummy};
+    if (!empty && !can_read && rank != dst_rank) {
+        HIPCHK(hipMalloc(&offs_dummy, sizeof(int32_t) * (size_t)(hi - lo + 1)));
+        HIPCHK(hipMemsetAsync(offs_dummy, 0, sizeof(int32_t) * (size_t)(hi - lo + 1), st));
+    }
+    const int32_t *offs_src = can_read ? d_offsets_mine : offs_dummy;
     int32_t mine_total = 0;
-    HIPCHK(hipMemcpyAsync(&mine_total, d_offsets_mine + (hi - lo), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (can_read) HIPCHK(hipMemcpyAsync(&mine_total, d_offsets_mine + (hi - lo), sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    int32_t my_ok = (mine_total >= 0 && mine_total <= packed_cap_mine) ? 1 : 0;    // m17gpu_pack_records drops rows beyond its packed_cap
+    // m17gpu_pack_records drops rows beyond its packed_cap: a total above the capacity is this rank's "no" as well
+    int32_t my_ok = (why_local.empty() && mine_total >= 0 && mine_total <= packed_cap_mine) ? 1 : 0;
+    if (!my_ok) mine_total = 0;
     HIPCHK(hipMemcpyAsync(ctx->d_flags, &my_ok, sizeof(int32_t), hipMemcpyHostToDevice, st));
     // leg 1: verdicts and local offset tables ([Cr] int32 each) to the gathering rank
     RCCLCHK(R.GroupStart());
@@ -863,7 +890,8 @@ int m17gpu_shard_gather_packed(m17gpu_ctx *ctx, void *comm, int rank, int world,
         }
     } else {
         RCCLGRP(R.Send(ctx->d_flags, 1, ncclInt32, dst_rank, cm, st));
-        if (hi > lo) RCCLGRP(R.Send(d_offsets_mine + 1, (size_t)(hi - lo), ncclInt32, dst_rank, cm, st));
+        // (a rank that says "no" for want of an offset table still sends one: the gathering rank's receive is posted by range)
+        if (hi > lo) RCCLGRP(R.Send(offs_src + 1, (size_t)(hi - lo), ncclInt32, dst_rank, cm, st));
     }
     RCCLGRP(R.GroupEnd());
     if (!grp_err.empty()) return fail(M17GPU_ERR_HIP, grp_err);
@@ -871,11 +899,11 @@ int m17gpu_shard_gather_packed(m17gpu_ctx *ctx, void *comm, int rank, int world,
     int32_t go = 1;
     std::string why;
     if (rank == dst_rank) {
-        if (hi > lo) HIPCHK(hipMemcpyAsync(d_offsets_all + lo + 1, d_offsets_mine + 1, (size_t)(hi - lo) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        if (hi > lo && can_read) HIPCHK(hipMemcpyAsync(d_offsets_all + lo + 1, d_offsets_mine + 1, (size_t)(hi - lo) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         for (int r = 0; r < world; ++r) {                       // each rank's total = its last local offset
             int a, b;
             m17gpu_shard_range(r, world, n_channels_total, &a, &b);
-            if (b > a) HIPCHK(hipMemcpyAsync(&totals[r], d_offsets_all + b, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            if (b > a && (r != dst_rank || can_read)) HIPCHK(hipMemcpyAsync(&totals[r], d_offsets_all + b, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             if (r != dst_rank) HIPCHK(hipMemcpyAsync(&oks[r], ctx->d_flags + 1 + r, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         }
         HIPCHK(hipStreamSynchronize(st));
@@ -883,7 +911,7 @@ int m17gpu_shard_gather_packed(m17gpu_ctx *ctx, void *comm, int rank, int world,
         long long sum = 0;
         for (int r = 0; r < world; ++r) {
             sum += totals[r];
-            if (!oks[r] && go) { go = 0; why = "rank " + std::to_string(r) + " packed more records than its d_packed_mine holds"; }
+            if (!oks[r] && go) { go = 0; why = "rank " + std::to_string(r) + (r == rank && !why_local.empty() ? ": " + why_local : " refused: its packed buffer is missing, of another context or too small for its records"); }
         }
         if (go && sum > packed_cap_all) { go = 0; why = "d_packed_all is too small for this step's records"; }
         HIPCHK(hipMemcpyAsync(ctx->d_flags, &go, sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -905,7 +933,7 @@ int m17gpu_shard_gather_packed(m17gpu_ctx *ctx, void *comm, int rank, int world,
     HIPCHK(hipStreamSynchronize(st));              // (dst_rank: the verdict's source word stays untouched until the sends have read it)
     if (!go)
         return fail(M17GPU_ERR_ARG, "m17gpu_shard_gather_packed: refused on every rank, nothing moved: " +
-                                    (why.empty() ? std::string("a packed buffer is too small for this step's records (see the gathering rank)") : why));
+                                    (!why_local.empty() ? why_local : why.empty() ? std::string("a packed buffer is too small for this step's records (see the gathering rank)") : why));
     // leg 2: the records themselves, sum(counts) rows per rank
     long long base = 0;
     RCCLCHK(R.GroupStart());

@@ -32,6 +32,11 @@ p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 res = [None] * world
 bar = threading.Barrier(world)
 
+def _range(r):
+    a, b = C.c_int(), C.c_int()
+    lib.m17gpu_shard_range(r, world, total, C.byref(a), C.byref(b))
+    return a.value, b.value
+
 def rank_main(rank):
     try:
         lo, hi = C.c_int(), C.c_int()
@@ -59,41 +64,48 @@ def rank_main(rank):
             pall = torch.zeros((total * cap, 64), dtype=torch.uint8, device="cuda") if rank == 0 else None
             oall = torch.full((total + 1,), -1, dtype=torch.int32, device="cuda") if rank == 0 else None
             totals = (C.c_int32 * world)()
+            if hi == lo:
+                packed = offs = None                             # a rank without channels: no buffers, capacity 0 -- but it CALLS
+            full_cap = int(packed.shape[0]) if packed is not None else 0
+            last = max(r for r in range(world) if _range(r)[1] > _range(r)[0])       # the last rank that has channels
 
-            def gather(cap_mine, cap_all):
-                return lib.m17gpu_shard_gather_packed(rx._ctx, comm, rank, world, 0, p(packed), cap_mine, p(offs), total,
-                                                      p(pall), cap_all, p(oall), totals, st)
-            if hi > lo:
-                # 1. the gathering rank's buffer too small: refused on EVERY rank, nothing left in the transport
-                bar.wait()
-                rc = gather(int(packed.shape[0]), 3)
-                out["small_all"] = (rc, lib.m17gpu_last_error().decode())
-                bar.wait()
-                out["pending_1"] = loop.loop_pending()
-                # 2. the LAST rank's own buffer too small (as if it had packed into 2 rows): refused on every rank
-                bar.wait()
-                rc = gather(2 if rank == world - 1 else int(packed.shape[0]), total * cap)
-                out["small_mine"] = (rc, lib.m17gpu_last_error().decode())
-                bar.wait()
-                out["pending_2"] = loop.loop_pending()
-                # 3. and the communicator is as good as new: the real gather
-                bar.wait()
-                rc = gather(int(packed.shape[0]), total * cap)
-                out["good"] = (rc, lib.m17gpu_last_error().decode())
-                stream.synchronize()
-                bar.wait()
-                out["pending_3"] = loop.loop_pending()
-                if rank == 0 and rc == 0:
-                    assert np.array_equal(oall.cpu().numpy(), want_offs), (oall.cpu().numpy(), want_offs)
-                    rows = pall.cpu().numpy()
-                    for c in range(total):
-                        assert rows[want_offs[c]:want_offs[c + 1]].tobytes() == whole["recs"][c, :whole["counts"][c]].tobytes(), c
-                    spans = []
-                    for r in range(world):
-                        a, b = C.c_int(), C.c_int()
-                        lib.m17gpu_shard_range(r, world, total, C.byref(a), C.byref(b))
-                        spans.append(int(whole["counts"][a.value:b.value].sum()))
-                    assert list(totals) == spans, (list(totals), spans)
+            def gather(cap_mine, cap_all, buffers=True):
+                return lib.m17gpu_shard_gather_packed(rx._ctx, comm, rank, world, 0, p(packed) if buffers else None, cap_mine,
+                                                      p(offs) if buffers else None, total, p(pall), cap_all, p(oall), totals, st)
+            # EVERY rank of the communicator makes every call, also one whose channel range is empty (world > channels)
+            # 1. the gathering rank's buffer too small: refused on EVERY rank, nothing left in the transport
+            bar.wait()
+            rc = gather(full_cap, 3)
+            out["small_all"] = (rc, lib.m17gpu_last_error().decode())
+            bar.wait()
+            out["pending_1"] = loop.loop_pending()
+            # 2. the last rank's own buffer too small (as if it had packed into 2 rows): refused on every rank
+            bar.wait()
+            rc = gather(2 if rank == last else full_cap, total * cap)
+            out["small_mine"] = (rc, lib.m17gpu_last_error().decode())
+            bar.wait()
+            out["pending_2"] = loop.loop_pending()
+            # 2b. that rank passes NO buffers at all (a rank-local argument error): its "no" travels with the verdicts, every
+            # rank returns together -- it used to return alone, in front of the exchange, and leave the gathering rank waiting
+            bar.wait()
+            rc = gather(0 if rank == last else full_cap, total * cap, buffers=(rank != last))
+            out["no_buffers"] = (rc, lib.m17gpu_last_error().decode())
+            bar.wait()
+            out["pending_2b"] = loop.loop_pending()
+            # 3. and the communicator is as good as new: the real gather
+            bar.wait()
+            rc = gather(full_cap, total * cap)
+            out["good"] = (rc, lib.m17gpu_last_error().decode())
+            stream.synchronize()
+            bar.wait()
+            out["pending_3"] = loop.loop_pending()
+            if rank == 0 and rc == 0:
+                assert np.array_equal(oall.cpu().numpy(), want_offs), (oall.cpu().numpy(), want_offs)
+                rows = pall.cpu().numpy()
+                for c in range(total):
+                    assert rows[want_offs[c]:want_offs[c + 1]].tobytes() == whole["recs"][c, :whole["counts"][c]].tobytes(), c
+                spans = [int(whole["counts"][_range(r)[0]:_range(r)[1]].sum()) for r in range(world)]
+                assert list(totals) == spans, (list(totals), spans)
         res[rank] = out
     except BaseException as e:                                   # noqa: BLE001 -- reported by the parent
         res[rank] = {"error": repr(e)}
@@ -110,14 +122,15 @@ for r, o in enumerate(res):
     assert o is not None and "error" not in o, (r, o)
     assert o["small_all"][0] == ERR_ARG and "refused on every rank" in o["small_all"][1], (r, o)
     assert o["small_mine"][0] == ERR_ARG and "refused on every rank" in o["small_mine"][1], (r, o)
+    assert o["no_buffers"][0] == ERR_ARG and "refused on every rank" in o["no_buffers"][1], (r, o)
     assert o["good"][0] == 0, (r, o)
-    assert o["pending_1"] == 0 and o["pending_2"] == 0 and o["pending_3"] == 0, (r, o)
+    assert o["pending_1"] == 0 and o["pending_2"] == 0 and o["pending_2b"] == 0 and o["pending_3"] == 0, (r, o)
 print("FANOUT_RANKS_OK", world, total)
 """
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,channels", [(2, 7), (3, 8)])
+@pytest.mark.parametrize("world,channels", [(2, 7), (3, 8), (4, 3)])          # (4, 3): world > channels, the last rank has none
 def test_capi_fanout_protocol_between_ranks_on_one_gpu(tmp_path, world, channels):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
