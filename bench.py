@@ -698,6 +698,7 @@ def run_rank(args):
     import torch
     import torch.distributed as dist
     import m17_sdr_amd as m
+    from m17_sdr_amd.shard import channel_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -756,7 +757,7 @@ def run_rank(args):
     # who took part, as each rank sees itself: its device (PCI bus id) and the channel range it owns -- the day a
     # scaling run happens, "did N ranks on N different GPUs each process their shard" is answerable from the line
     me = {"rank": rank, "local_rank": local, "host": socket.gethostname(), "device": local, "pci_bus_id": pci_bus_id(torch, local),
-          "shard_range": list(m.shard.channel_range(rank, world, world * C)), "channels": C}
+          "shard_range": list(channel_range(rank, world, world * C)), "channels": C}
     if world > 1:
         ranks = [None] * world
         dist.all_gather_object(ranks, me)

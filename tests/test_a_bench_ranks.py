@@ -39,7 +39,6 @@ def test_bench_starts_its_own_ranks_gloo_rehearsal():
     assert all(r["pci_bus_id"] for r in line["ranks"]) and line["collectives"]["world_size"] == 2
     assert line["collectives"]["distinct_devices"] == 1                     # the rehearsal: two ranks on this box's one card
     assert 0 < line["roofline"]["frac_wall"] <= line["roofline"]["frac"] * 1.02 and line["roofline"]["path"]["fir"] in (1, 5)
-    assert 0 < line["fir_stage"]["frac_wall"] and line["fir_stage"]["path"]["fir"] == 5
 
 
 def test_bench_drives_the_capi_fanout_entries():
