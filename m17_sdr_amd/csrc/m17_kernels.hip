@@ -101,10 +101,27 @@ __device__ __forceinline__ void limit(float &re, float &im)
 #ifdef M17_REF_ARITH
     limit_ref(re, im);
 #else
+#ifdef M17_LIMIT_NO_RCP
+    // EXPERIMENT (round 6, profiles/r06_limiter_three_newton_steps.txt; build: make norcp): 1 / m without v_rcp_f32 -- three
+    // Newton steps from the v_rsq_f32 value the square root already has.  Two steps leave 432 of the 2^32 int16 pairs on the
+    // wrong side of a rounding boundary (r05_limiter_without_rcp.txt); the third is the residual fix-up of the round-5 review.
+    const float a = re * re + im * im;
+    const float q = __builtin_amdgcn_rsqf(a);
+    const float y0 = a * q;
+    const float r = __builtin_fmaf(-y0, y0, a);
+    const float m = __builtin_fmaf(r, q * 0.5f, y0);
+    float g = q;
+    g = __builtin_fmaf(__builtin_fmaf(-m, g, 1.0f), g, g);
+    g = __builtin_fmaf(__builtin_fmaf(-m, g, 1.0f), g, g);
+    g = __builtin_fmaf(__builtin_fmaf(-m, g, 1.0f), g, g);
+    re = re * g;
+    im = im * g;
+#else
     const float m = sqrt_rn_normal(re * re + im * im);
     const float g = rcp_rn_normal(m);
     re = re * g;
     im = im * g;
+#endif
 #endif
 }
 
@@ -430,12 +447,26 @@ __device__ __forceinline__ void fe_convert(const uint32_t *w, v2f *z)
     for (int p = 0; p < N / 2; ++p) R[p] = __builtin_elementwise_fma(-Y[p], Y[p], A[p]);
 #pragma unroll
     for (int p = 0; p < N / 2; ++p) M[p] = __builtin_elementwise_fma(R[p], Q[p], Y[p]);
+#ifdef M17_LIMIT_NO_RCP
+    // EXPERIMENT (see limit()): three packed Newton steps from the rsq value instead of v_rcp_f32 + one
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) G[p] = (v2f){r[2 * p], r[2 * p + 1]};
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+#pragma unroll
+        for (int p = 0; p < N / 2; ++p) E[p] = __builtin_elementwise_fma(-M[p], G[p], one);
+#pragma unroll
+        for (int p = 0; p < N / 2; ++p) G[p] = __builtin_elementwise_fma(E[p], G[p], G[p]);
+    }
+    (void)R0;
+#else
 #pragma unroll
     for (int p = 0; p < N / 2; ++p) R0[p] = (v2f){__builtin_amdgcn_rcpf(M[p].x), __builtin_amdgcn_rcpf(M[p].y)};
 #pragma unroll
     for (int p = 0; p < N / 2; ++p) E[p] = __builtin_elementwise_fma(-M[p], R0[p], one);        // rcp_rn_normal
 #pragma unroll
     for (int p = 0; p < N / 2; ++p) G[p] = __builtin_elementwise_fma(E[p], R0[p], R0[p]);
+#endif
 #pragma unroll
     for (int p = 0; p < N / 2; ++p) { z[2 * p] = x[2 * p] * (v2f){G[p].x, G[p].x}; z[2 * p + 1] = x[2 * p + 1] * (v2f){G[p].y, G[p].y}; }
 }
