@@ -462,6 +462,61 @@ def pci_bus_id(torch, device):
     return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
 
 
+def two_contexts_leg(args, torch, device, C, nblk):
+    """What a HOST can have that a call cannot: the same channels as TWO contexts of C / 2 each, free-running
+    on two streams -- each context's steps back to back on its own stream, no join per step -- so that one context's decoder
+    runs beside the other's FIR stage across step boundaries and fills the tail of its kernel.  Same kernels, same results per
+    channel (contexts are independent); wall clock per step of all C channels.  Not the headline: `value` keeps one context on one
+    stream, where a kernel's HIP-event duration is what it takes alone."""
+    import m17_sdr_amd as m
+    steps, warm, parts = 20, 3, 2
+    n = C // parts
+    rxs = [m.Receiver(n, nblk, device=device) for _ in range(parts)]
+    for rx in rxs:
+        rx.set_option("fir_impl", 4)        # the library picks its kernels by a context's own channel count; the GPU carries C channels here
+        for kv in args.option:
+            name, value = kv.split("=")
+            rx.set_option(name, int(value))
+    T = steps + warm
+    slabs = []
+    for p, rx in enumerate(rxs):
+        big = rx.gen_batch(nblk * T, n_stream_frames=40, ebn0_db=200.0, first_channel=p * n)["iq"]
+        torch.cuda.synchronize(device)
+        sl = torch.empty((T, n, nblk, 1920, 2), dtype=torch.int16, device=big.device)
+        sl.copy_(big.view(n, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4))
+        del big
+        slabs.append(sl)
+    outs = [rx.alloc_outputs(nblk) for rx in rxs]
+    streams = [torch.cuda.Stream(device=device) for _ in range(parts)]
+
+    def run(k0, k1):
+        for k in range(k0, k1):
+            for p in range(parts):
+                with torch.cuda.stream(streams[p]):
+                    rxs[p].rx_blocks(slabs[p][k % T], 1, outs[p])
+    t_end = time.perf_counter() + 0.4
+    while time.perf_counter() < t_end:                       # whole passes of the stream: it stays continuous per context
+        run(0, T)
+        torch.cuda.synchronize(device)
+    run(0, warm)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    run(warm, warm + steps)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    path = rxs[0].last_path()
+    for rx in rxs:
+        rx.close()
+    del slabs
+    torch.cuda.empty_cache()
+    ms = dt / steps * 1e3
+    return {"workload": f"full chain, {C:,} channels as {parts} contexts of {n:,} on {parts} streams, free-running (no join per step), {nblk} blocks per step, noiseless",
+            "ms": round(ms, 4), "value": round(C * nblk * 192 * steps / dt / 1e6, 3), "unit": "Msym/s",
+            "frac_wall": round(BYTES_FULL * C * nblk / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "path": path, "steps": steps, "warmup": warm,
+            "note": "a host-side choice the C-ABI allows (contexts are independent); kernels of the two contexts overlap, so there is "
+                    "no per-kernel time here"}
+
+
 def host_cores():
     """(threads this job may use, physical cores and SMT threads of the host as /proc/cpuinfo lists them)."""
     try:
@@ -853,6 +908,8 @@ def run_rank(args):
             line["noisy"] = noisy_leg(args, torch, local, C, nblk)
         if world == 1 and not args.no_step12 and mode == 1 and (C, nblk) == (16384, 16) and args.ebn0 >= 100.0:
             line["step_12_blocks"] = step12_leg(args, torch, local, C)
+        if world == 1 and not args.no_step12 and mode == 1 and (C, nblk) == (16384, 16) and args.ebn0 >= 100.0:
+            line["two_contexts"] = two_contexts_leg(args, torch, local, C, nblk)
         if world == 1 and not args.no_fir_stage and mode == 1:
             line["fir_stage"] = fir_stage(args, torch, local)
             line["fir_stage_16384"] = fir_stage(args, torch, local, C=16384, nblk=16, steps=20, warm=3)
