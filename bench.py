@@ -452,10 +452,14 @@ def pci_bus_id(torch, device):
     """PCI bus id of the HIP device (domain:bus:device.function), through the runtime torch runs on."""
     import ctypes as C
     try:
-        hip = C.CDLL("libamdhip64.so")
-        buf = C.create_string_buffer(32)
-        if hip.hipDeviceGetPCIBusId(buf, 32, int(device)) == 0:
-            return buf.value.decode()
+        # the copy of the HIP runtime this process already runs on (torch's), by its path: dlopen of a path that is
+        # loaded returns that library -- never a second runtime beside it (INTEGRATION.md "One HIP runtime per process")
+        path = next((ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln), None)
+        if path:
+            hip = C.CDLL(path)
+            buf = C.create_string_buffer(32)
+            if hip.hipDeviceGetPCIBusId(buf, 32, int(device)) == 0:
+                return buf.value.decode()
     except OSError:
         pass
     p = torch.cuda.get_device_properties(device)

@@ -1,4 +1,4 @@
-"""A/B of the FIR-stage variants on one box: fir_impl 1 (front end + timing kernel) against 2 (fused), same input, same
+"""A/B of the FIR-stage variants on one box: fir_impl 1 (front end + timing kernel) against 4 (k_rx_chan6), same input, same
 process.  usage: python scripts/ab_fir.py [channels] [blocks] [mode]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,7 @@ slabs.copy_(big.view(C, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4))
 del big
 gen.close()
 for rep in range(2):
-    for impl in (1, 2):
+    for impl in (1, 4):
         rx = m.Receiver(C, nblk)
         rx.set_option("fir_impl", impl)
         out = rx.alloc_outputs(nblk, want_syms=(mode == 0))

@@ -10,7 +10,7 @@ Cn = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 nblk, T = 12, 6
 rx = m.Receiver(Cn, nblk)
-rx.set_option("sync_impl", 7)
+rx.set_option("sync_impl", 8)
 big = rx.gen_batch(nblk * T)["iq"]
 slabs = big.view(Cn, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4).contiguous()
 del big

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import m17_sdr_amd as m
 C, nblk = 16384, 12
 rxA, rxB = m.Receiver(C, nblk), m.Receiver(C, nblk)
-rxB.set_option("sync_impl", 7)
+rxB.set_option("sync_impl", 8)
 iq = rxA.gen_batch(nblk)["iq"]
 disc, offs = rxB.frontend(iq)
 outB = rxB.alloc_outputs(nblk)

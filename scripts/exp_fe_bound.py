@@ -14,7 +14,7 @@ for rnd in range(2):
     for dbg in (0, 1, 2, 3):
         rx = m.Receiver(C, nblk)
         rx.set_option("fe_debug", dbg)
-        rx.set_option("sync_impl", 7)
+        rx.set_option("sync_impl", 8)
         out = rx.alloc_outputs(nblk)
         for k in range(2): rx.rx_blocks(slabs[k], 0, out)
         torch.cuda.synchronize()

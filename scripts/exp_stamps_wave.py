@@ -7,7 +7,7 @@ import m17_sdr_amd as m
 Cn, nblk, T = int(sys.argv[2]) if len(sys.argv) > 2 else 16384, 12, int(os.environ.get('M17_STEPS', '4'))
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rx = m.Receiver(Cn, nblk)
-rx.set_option("sync_impl", 7)
+rx.set_option("sync_impl", 8)
 ebn0 = float(sys.argv[3]) if len(sys.argv) > 3 else 200.0
 big = rx.gen_batch(nblk * T, ebn0_db=ebn0, noise_cutoff_hz=6250.0 if ebn0 < 100 else 0.0)["iq"]
 slabs = big.view(Cn, T, nblk, 1920, 2).permute(1, 0, 2, 3, 4).contiguous()
