@@ -571,10 +571,12 @@ def test_pluto_decimator_bit_exact_and_streaming():
         rx.close()
 
 
-@pytest.mark.parametrize("nblk", [2, 4, 5, 7, 8, 13])
+@pytest.mark.parametrize("nblk", [2, 4, 5, 7, 8, 9, 11, 12, 13, 17, 28, 29])
 def test_short_calls_on_the_three_wave_kernel(nblk):
     """Calls of up to eight blocks start on four-row tiles (frontend_quick4p): rows 0-3 on the front-end wave, 4-7 on
-    the framer wave; the default up to 1,024 channels, and forced here too so that a policy change cannot hide it."""
+    the framer wave; longer ones run sixteen-row tiles from the first row on.  Block counts on every side of those
+    boundaries (4 / 8, 16, 16 + 12); the default up to 1,024 channels, and forced here too so that a policy change cannot
+    hide it."""
     for opts in (None, {"fir_impl": 5}):
         _rx_compare(C=37, nblk=nblk, mode=1, ebn0=200.0, nsf=10, calls=4, options=opts)
         _rx_compare(C=21, nblk=nblk, mode=1, ebn0=7.0, nsf=6, calls=3, options=opts)
