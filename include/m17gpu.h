@@ -221,7 +221,13 @@ int m17gpu_get_golay_tables(uint16_t *h_enc /* [4096] */, uint16_t *h_err /* [40
  * "derand_bits" u8[368] (m17_correlate.cpp:3-7,35-42), "golay_rows" u16[12] (m17_golay.cpp:11),
  * "punc1" u8[61] / "punc2" u8[12] / "punc3" u8[8] (m17_puncture.cpp:4-10), "butterfly" u8[16][5] =
  * the BF(v,w,x,y,z) rows (m17_conv.cpp:93-108), "crc_poly" u16 (m17_crc.cpp:4), "tx_lut" float[4]
- * (m17_modulate.cpp:9), "sync_words" u16[4] link/stream/packet/BERT (m17_tx_routines.cpp:6-9). */
+ * (m17_modulate.cpp:9), "sync_words" u16[4] link/stream/packet/BERT (m17_tx_routines.cpp:6-9), "rx_literals" double[24] =
+ * the literals and control constants of the streaming arithmetic, each under the one name the kernels use it by (int16 scale
+ * 0.00003 m17_dsp.cpp:138, demapper 0.6666 :41 and 8.0 :88 over 8 sync symbols :85, discriminator 0.5 :199 and % 5 :207, limiter
+ * 1.0 / m :415, thresholds 10 / 80 m17_rx_sync.cpp:93,95, % 2 :82, initial m_clk 1 / m_thr 0 / m_index 10 :123-126, framer gates
+ * votes > 0 / < 0.3 and votes > 1 / < 0.5 m17_rx_frame.cpp:83-98, N_FERROR 5 :122, m_fclk 8 :166, Viterbi m_acm[0] 1.0 and
+ * state & 0x08 m17_conv.cpp:153,165, Golay table fill 0xFFF / 0x400 / bits < 5 m17_golay.cpp:53-61): tests/test_ref_constants.py
+ * holds them against the values extracted from the reference's source text. */
 int m17gpu_get_constant(const char *name, void *h_out, int cap_bytes);
 
 /* ---------------- output wire format (host) ----------------
